@@ -1,0 +1,426 @@
+// Per-ensemble-member dense nonsymmetric complex eigen-solver (replaces scipy.linalg.eig
+// at reference kbdm.py:192, LAPACK zgeev there).  One workgroup owns one n x n matrix.
+//
+// Only (mu_k, p_k) pairs are consumed downstream (kbdm.py:198-236: each eigenvector is
+// normalised on its own and its overall scale cancels), so instead of a full Schur form
+// with accumulated Schur vectors we compute
+//   1. Householder Hessenberg reduction  W = Qh H Qh^H               (gehd2 / gen_qh)
+//   2. eigenvalues of H by single-shift complex QR on the ACTIVE block only
+//      (LAPACK zlahqr with wantt = wantz = false)                      (hqr_eigvals)
+//   3. one eigenvector per eigenvalue by inverse iteration on H (LAPACK zlaein: LU of
+//      H - w I with adjacent-row pivoting + one triangular solve), one wavefront per
+//      eigenvalue, embarrassingly parallel                             (invit)
+//   4. back-transformation p_k = Qh x_k (done by the batched zgemm kernel).
+// Column-major storage, leading dimension ld.
+#pragma once
+#include "kb_ctx.hpp"
+#include "kb_svd.hpp"
+
+namespace kb {
+
+KB_HD int gehd2_scratch_bytes(int n, int nwaves, int ws) {
+    int z = n > nwaves * ws ? n : nwaves * ws;
+    return (n + z) * (int)sizeof(cd);
+}
+
+// Hessenberg reduction: W = Qh H Qh^H, Qh = H_0 ... H_{n-3}; reflector k stored in
+// W[k+2.., k] (v[0] = 1 at row k+1); the subdiagonal W[k+1,k] becomes real.
+template <class C>
+KB_HD void gehd2(const C& ctx, int n, cd* W, int ld, cd* tauh) {
+    cd* vv = reinterpret_cast<cd*>(ctx.scratch());
+    cd* zp = vv + n;
+    for (int k = 0; k < n - 2; ++k) {
+        cd* col = &W[(k + 1) + (size_t)k * ld];
+        const int nv = n - k - 1;
+        double beta;
+        cd tau;
+        larfg(ctx, nv, col, beta, tau);
+        ctx.sync();
+        // right: W[0:n, k+1:n] -= tau (W v) v^H  with v = [1; col[1..]]
+        if (!is_zero(tau)) {
+            for (int i = ctx.tid(); i < nv; i += ctx.nthreads()) vv[i] = (i == 0) ? mk(1.0, 0.0) : col[i];
+            ctx.sync();
+            apply_right(ctx, n, nv, vv, tau, &W[(size_t)(k + 1) * ld], ld, zp);
+            ctx.sync();
+            // left: W[k+1:n, k+1:n] = (I - conj(tau) v v^H) W[k+1:n, k+1:n]
+            apply_left(ctx, nv, nv, col, conj(tau), &W[(k + 1) + (size_t)(k + 1) * ld], ld);
+        }
+        ctx.sync();
+        if (ctx.tid() == 0) { tauh[k] = tau; col[0] = mk(beta, 0.0); }
+        ctx.sync();
+    }
+}
+
+// Qh = H_0 ... H_{n-3} explicit (n x n); reflectors act on indices >= 1.
+template <class C>
+KB_HD void gen_qh(const C& ctx, int n, const cd* W, int ld, const cd* tauh, cd* Q, int ldq) {
+    for (int idx = ctx.tid(); idx < n * n; idx += ctx.nthreads()) {
+        const int i = idx % n, j = idx / n;
+        Q[i + (size_t)j * ldq] = (i == j) ? mk(1.0, 0.0) : czero();
+    }
+    ctx.sync();
+    for (int k = n - 3; k >= 0; --k) {
+        const cd tau = tauh[k];
+        const int nv = n - k - 1;
+        if (!is_zero(tau))
+            apply_left(ctx, nv, nv, &W[(k + 1) + (size_t)k * ld], tau, &Q[(k + 1) + (size_t)(k + 1) * ldq], ldq);
+        ctx.sync();
+    }
+}
+
+// Extract the upper Hessenberg part into a work copy Hc (for the QR iteration) and its
+// transpose Ht (Ht[j + i*ld] = H[i,j]; rows of H contiguous, for the inverse iteration).
+template <class C>
+KB_HD void hess_copies(const C& ctx, int n, const cd* W, int ld, cd* Hc, int ldc, cd* Ht, int ldt) {
+    for (int idx = ctx.tid(); idx < n * n; idx += ctx.nthreads()) {
+        const int i = idx % n, j = idx / n;
+        const cd v = (i <= j + 1) ? W[i + (size_t)j * ld] : czero();
+        Hc[i + (size_t)j * ldc] = v;
+    }
+    for (int idx = ctx.tid(); idx < n * n; idx += ctx.nthreads()) {
+        const int j = idx % n, i = idx / n;   // consecutive threads -> consecutive j (coalesced store)
+        const cd v = (i <= j + 1) ? W[i + (size_t)j * ld] : czero();
+        Ht[j + (size_t)i * ldt] = v;
+    }
+    ctx.sync();
+}
+
+// 2-element Householder (zlarfg with n = 2), scalar.
+KB_HD void larfg2(cd& alpha, cd& x, cd& tau) {
+    const double xn = cabs(x);
+    if (xn == 0.0 && alpha.y == 0.0) { tau = czero(); return; }
+    const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn * xn);
+    const double beta = (alpha.x >= 0.0) ? -nrm : nrm;
+    tau = mk((beta - alpha.x) / beta, -alpha.y / beta);
+    x = cdiv(x, mk(alpha.x - beta, alpha.y));
+    alpha = mk(beta, 0.0);
+}
+
+// Eigenvalues of the upper Hessenberg H (destroyed).  LAPACK zlahqr, eigenvalues only:
+// every transformation touches the active block H[l..i, l..i] alone.
+// All threads execute the same control flow (every decision is taken on values read
+// after a barrier, or on block reductions that return identical bits to every thread).
+template <class C>
+KB_HD void hqr_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info) {
+#define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
+    const double ulp = KB_ULP;
+    const double smlnum = KB_SAFMIN * ((double)n / ulp);
+    const int tid = ctx.tid(), nt = ctx.nthreads();
+    int fail = 0;
+    if (n == 1) {
+        if (tid == 0) { w[0] = HH(0, 0); *info = 0; }
+        ctx.sync();
+        return;
+    }
+    // make every subdiagonal real (diagonal unitary similarity; eigenvalues unchanged)
+    for (int i = 1; i < n; ++i) {
+        ctx.sync();
+        const cd hs = HH(i, i - 1);
+        if (hs.y != 0.0) {
+            const double a = cabs(hs);
+            const cd sc = mk(hs.x / a, -hs.y / a);   // conj(hs)/|hs|
+            ctx.sync();                               // everyone has read hs
+            if (tid == 0) {
+                HH(i, i - 1) = mk(a, 0.0);
+                if (i + 1 < n) HH(i + 1, i) = HH(i + 1, i) * conj(sc);
+            }
+            for (int j = i + 1 + tid; j < n; j += nt) HH(i, j) = HH(i, j) * sc;        // row i
+            for (int r = tid; r < i; r += nt) HH(r, i) = HH(r, i) * conj(sc);          // column i
+        }
+    }
+    ctx.sync();
+    const int itmax = 30 * (n > 10 ? n : 10);
+    int kdefl = 0;
+    int i = n - 1;
+    while (i >= 0) {
+        int l = 0;
+        bool converged = false;
+        for (int its = 0; its <= itmax; ++its) {
+            // ---- look for a single small subdiagonal element: largest k in (l, i]
+            int kf = l;
+            for (int k = l + 1 + tid; k <= i; k += nt) {
+                const cd hkk1 = HH(k, k - 1);
+                bool small_ = false;
+                if (cabs1(hkk1) <= smlnum) small_ = true;
+                else {
+                    double tst = cabs1(HH(k - 1, k - 1)) + cabs1(HH(k, k));
+                    if (tst == 0.0) {
+                        if (k - 2 >= 0) tst += fabs(HH(k - 1, k - 2).x);
+                        if (k + 1 <= n - 1) tst += fabs(HH(k + 1, k).x);
+                    }
+                    if (fabs(hkk1.x) <= ulp * tst) {
+                        const double a1 = cabs1(hkk1), a2 = cabs1(HH(k - 1, k));
+                        const double ab = fmax(a1, a2), ba = fmin(a1, a2);
+                        const cd df = HH(k - 1, k - 1) - HH(k, k);
+                        const double b1 = cabs1(HH(k, k)), b2 = cabs1(df);
+                        const double aa = fmax(b1, b2), bb = fmin(b1, b2);
+                        const double s = aa + ab;
+                        if (ba * (ab / s) <= fmax(smlnum, ulp * (bb * (aa / s)))) small_ = true;
+                    }
+                }
+                if (small_ && k > kf) kf = k;
+            }
+            kf = ctx.block_max(kf);
+            l = kf;
+            if (l > 0 && tid == 0) HH(l, l - 1) = czero();
+            if (l >= i) { converged = true; break; }
+            ctx.sync();
+            kdefl++;
+            // ---- shift
+            cd t;
+            if (kdefl % 20 == 0) {
+                const double s = 0.75 * fabs(HH(i, i - 1).x);
+                t = mk(s, 0.0) + HH(i, i);
+            } else if (kdefl % 10 == 0) {
+                const double s = 0.75 * fabs(HH(l + 1, l).x);
+                t = mk(s, 0.0) + HH(l, l);
+            } else {
+                t = HH(i, i);
+                const cd u = csqrt_(HH(i - 1, i)) * csqrt_(HH(i, i - 1));
+                double s = cabs1(u);
+                if (s != 0.0) {
+                    const cd x = 0.5 * (HH(i - 1, i - 1) - t);
+                    const double sx = cabs1(x);
+                    s = fmax(s, sx);
+                    const cd xs = mk(x.x / s, x.y / s), us = mk(u.x / s, u.y / s);
+                    cd y = s * csqrt_(xs * xs + us * us);
+                    if (sx > 0.0) {
+                        const cd xn = mk(x.x / sx, x.y / sx);
+                        if (xn.x * y.x + xn.y * y.y < 0.0) y = -y;
+                    }
+                    t = t - u * cdiv(u, x + y);
+                }
+            }
+            // ---- look for two consecutive small subdiagonals: largest ms in [l+1, i-1]
+            int mf = l;
+            for (int mm = l + 1 + tid; mm <= i - 1; mm += nt) {
+                const cd h11 = HH(mm, mm), h22 = HH(mm + 1, mm + 1);
+                cd h11s = h11 - t;
+                double h21 = HH(mm + 1, mm).x;
+                const double s = cabs1(h11s) + fabs(h21);
+                h11s = mk(h11s.x / s, h11s.y / s);
+                h21 = h21 / s;
+                const double h10 = HH(mm, mm - 1).x;
+                if (fabs(h10) * fabs(h21) <= ulp * (cabs1(h11s) * (cabs1(h11) + cabs1(h22))))
+                    if (mm > mf) mf = mm;
+            }
+            mf = ctx.block_max(mf);
+            const int ms = mf;
+            cd v1, v2;
+            {
+                cd h11s = HH(ms, ms) - t;
+                double h21 = HH(ms + 1, ms).x;
+                const double s = cabs1(h11s) + fabs(h21);
+                v1 = mk(h11s.x / s, h11s.y / s);
+                v2 = mk(h21 / s, 0.0);
+            }
+            // ---- single-shift QR sweep on rows/cols l..i
+            for (int k = ms; k <= i - 1; ++k) {
+                if (k > ms) { v1 = HH(k, k - 1); v2 = HH(k + 1, k - 1); }
+                cd t1;
+                larfg2(v1, v2, t1);
+                ctx.sync();  // everyone has read H(k,k-1), H(k+1,k-1)
+                if (k > ms && tid == 0) { HH(k, k - 1) = v1; HH(k + 1, k - 1) = czero(); }
+                const double t2 = (t1 * v2).x;
+                // rows k, k+1 ; columns k..i
+                for (int j = k + tid; j <= i; j += nt) {
+                    const cd a = HH(k, j), b = HH(k + 1, j);
+                    const cd sum = conj(t1) * a + t2 * b;
+                    HH(k, j) = a - sum;
+                    HH(k + 1, j) = b - sum * v2;
+                }
+                ctx.sync();
+                // columns k, k+1 ; rows l..min(k+2, i)
+                const int rmax = (k + 2 < i) ? k + 2 : i;
+                for (int j = l + tid; j <= rmax; j += nt) {
+                    const cd a = HH(j, k), b = HH(j, k + 1);
+                    const cd sum = t1 * a + t2 * b;
+                    HH(j, k) = a - sum;
+                    HH(j, k + 1) = b - sum * conj(v2);
+                }
+                ctx.sync();
+                if (k == ms && ms > l) {
+                    // the sweep started below l: make H(ms, ms-1) real again
+                    cd temp = mk(1.0, 0.0) - t1;
+                    const double at = cabs(temp);
+                    temp = mk(temp.x / at, temp.y / at);
+                    if (tid == 0) {
+                        HH(ms + 1, ms) = HH(ms + 1, ms) * conj(temp);
+                        if (ms + 2 <= i) HH(ms + 2, ms + 1) = HH(ms + 2, ms + 1) * temp;
+                    }
+                    ctx.sync();
+                    // rows j in S scale (j, c>j) by temp; columns j in S scale (r<j, j) by
+                    // conj(temp); S = {ms..i} \ {ms+1}.  One combined factor per element.
+                    {
+                        const int len = i - l + 1;
+                        for (int idx = tid; idx < len * len; idx += nt) {
+                            const int r = l + idx % len, c = l + idx / len;
+                            if (r < c) {
+                                const bool rin = (r >= ms && r != ms + 1);
+                                const bool cin = (c >= ms && c != ms + 1);
+                                if (rin || cin) {
+                                    cd v = HH(r, c);
+                                    if (rin) v = v * temp;
+                                    if (cin) v = v * conj(temp);
+                                    HH(r, c) = v;
+                                }
+                            }
+                        }
+                    }
+                    ctx.sync();
+                }
+            }
+            // ---- ensure H(i, i-1) is real
+            {
+                cd temp = HH(i, i - 1);
+                ctx.sync();
+                if (temp.y != 0.0) {
+                    const double rt = cabs(temp);
+                    if (tid == 0) HH(i, i - 1) = mk(rt, 0.0);
+                    temp = mk(temp.x / rt, temp.y / rt);
+                    for (int r = l + tid; r <= i - 1; r += nt) HH(r, i) = HH(r, i) * temp;
+                    ctx.sync();
+                }
+            }
+        }
+        if (!converged) { fail = 1; }
+        ctx.sync();
+        if (tid == 0) w[i] = HH(i, i);
+        if (!converged) {
+            // give up on this block: report remaining diagonal entries (flagged via info)
+            for (int r = l + tid; r < i; r += nt) w[r] = HH(r, r);
+            i = l - 1;
+        } else {
+            i = l - 1;
+        }
+        kdefl = 0;
+        ctx.sync();
+    }
+    if (tid == 0) *info = fail;
+    ctx.sync();
+#undef HH
+}
+
+// ---------------------------------------------------------------------------------
+// Inverse iteration for the right eigenvectors of the upper Hessenberg H (given through
+// its transpose Ht: row i of H is contiguous at Ht + i*ldt).  One wavefront per
+// eigenvalue.  LAPACK zhsein/zlaein semantics: eigenvalues closer than eps3 to an
+// earlier one are perturbed; pivots that vanish are replaced by eps3; the start vector
+// is eps3*ones; a single back-substitution normally reaches the growth criterion.
+//   UT   : per-wavefront workspace, n*n entries each (row i of the U factor contiguous)
+//   X    : n x n output, column k = eigenvector of w[k] in the Hessenberg basis
+// flags[k] = 1 if the growth criterion was not met after the retries.
+KB_HD int invit_scratch_bytes_per_wave(int n) { return 2 * n * (int)sizeof(cd); }
+
+template <class C>
+KB_HD void invit(const C& ctx, int n, const cd* Ht, int ldt, const cd* w, double hnorm, cd* UTall,
+                 cd* X, int ldx, int nwaves_used, int* weak) {
+    const int lane = ctx.lane();
+    const double eps3 = fmax(hnorm * KB_ULP, KB_SAFMIN * ((double)n / KB_ULP));
+    const double rootn = sqrt((double)n);
+    const double growto = 0.1 / rootn;
+    if (ctx.wave() >= nwaves_used) return;
+    cd* rowc = reinterpret_cast<cd*>(ctx.scratch()) + (size_t)ctx.wave() * 2 * n;
+    cd* x = rowc + n;
+    cd* UT = UTall + (size_t)ctx.wave() * n * n;
+    int nweak = 0;
+    for (int kk = ctx.wave(); kk < n; kk += nwaves_used) {
+        // perturb wk away from earlier (index < kk) eigenvalues closer than eps3
+        cd wk = w[kk];
+        {
+            int cnt = 0;
+            for (int q = lane; q < kk; q += C::WS) cnt += (cabs1(w[q] - w[kk]) < eps3) ? 1 : 0;
+            cnt = (int)ctx.wave_sum((double)cnt);
+            wk.x += cnt * eps3;
+        }
+        // ---- LU of B = H - wk I with adjacent-row pivoting; row i of U -> UT[i*n + j]
+        for (int j = lane; j < n; j += C::WS) {
+            cd v = Ht[j];
+            if (j == 0) v = v - wk;
+            rowc[j] = v;
+        }
+        ctx.wave_fence();
+        for (int i = 0; i < n - 1; ++i) {
+            const cd ei = Ht[i + (size_t)(i + 1) * ldt];   // H(i+1, i)
+            cd bii = rowc[i];
+            const cd* hrow = Ht + (size_t)(i + 1) * ldt;
+            if (cabs1(bii) < cabs1(ei)) {
+                const cd xm = cdiv(bii, ei);
+                for (int j = i + 1 + lane; j < n; j += C::WS) {
+                    cd temp = hrow[j];
+                    if (j == i + 1) temp = temp - wk;
+                    UT[(size_t)i * n + j] = temp;
+                    rowc[j] = rowc[j] - xm * temp;
+                }
+                if (lane == 0) UT[(size_t)i * n + i] = ei;
+            } else {
+                if (is_zero(bii)) bii = mk(eps3, 0.0);
+                const cd xm = cdiv(ei, bii);
+                for (int j = i + 1 + lane; j < n; j += C::WS) {
+                    cd temp = hrow[j];
+                    if (j == i + 1) temp = temp - wk;
+                    const cd cur = rowc[j];
+                    UT[(size_t)i * n + j] = cur;
+                    rowc[j] = temp - xm * cur;
+                }
+                if (lane == 0) UT[(size_t)i * n + i] = bii;
+            }
+            ctx.wave_fence();
+        }
+        {
+            cd bnn = rowc[n - 1];
+            if (is_zero(bnn)) bnn = mk(eps3, 0.0);
+            if (lane == 0) UT[(size_t)(n - 1) * n + (n - 1)] = bnn;
+        }
+        ctx.wave_fence();
+        // ---- solve U x = v (v = eps3 * start vector); retry with other start vectors
+        bool ok = false;
+        for (int its = 0; its < 4 && !ok; ++its) {
+            for (int j = lane; j < n; j += C::WS) {
+                double vj;
+                if (its == 0) vj = eps3;
+                else {
+                    const double rtemp = eps3 / (rootn + 1.0);
+                    vj = (j == 0) ? eps3 : rtemp;
+                    if (j == n - its) vj -= eps3 * rootn;
+                }
+                x[j] = mk(vj, 0.0);
+            }
+            ctx.wave_fence();
+            bool rescaled = false;
+            for (int i = n - 1; i >= 0; --i) {
+                const cd* urow = UT + (size_t)i * n;
+                cd s = czero();
+                for (int j = i + 1 + lane; j < n; j += C::WS) cfma(s, urow[j], x[j]);
+                s = ctx.wave_sum(s);
+                cd xi = cdiv(x[i] - s, urow[i]);
+                const double mag = cabs1(xi);
+                if (mag > 1e120) {
+                    // rescale the whole system (solution so far and untouched right-hand side)
+                    const double sc = 1e-120;
+                    for (int j = lane; j < n; j += C::WS) x[j] = x[j] * sc;
+                    xi = xi * sc;
+                    rescaled = true;
+                    ctx.wave_fence();
+                }
+                if (lane == 0) x[i] = xi;
+                ctx.wave_fence();
+            }
+            double vn = 0.0;
+            for (int j = lane; j < n; j += C::WS) vn += cabs1(x[j]);
+            vn = ctx.wave_sum(vn);
+            ok = rescaled || (vn >= growto);
+        }
+        if (!ok) nweak++;
+        // ---- normalise to unit max-|.|_1 entry and store
+        double mx = 0.0;
+        for (int j = lane; j < n; j += C::WS) mx = fmax(mx, cabs1(x[j]));
+        mx = ctx.wave_max(mx);
+        const double inv = (mx > 0.0) ? 1.0 / mx : 1.0;
+        for (int j = lane; j < n; j += C::WS) X[j + (size_t)kk * ldx] = x[j] * inv;
+        ctx.wave_fence();
+    }
+    if (lane == 0 && nweak > 0) *weak = 1;   // benign race: every writer stores 1
+}
+
+}  // namespace kb

@@ -1,0 +1,151 @@
+// CPU debugging harness for the per-member algorithms in llckbdm_amd/csrc/kb_*.hpp.
+//
+// TEST INFRASTRUCTURE ONLY.  It instantiates the very same templates the HIP kernels
+// instantiate, but with kb::HostCtx (a one-thread "workgroup"), so that indexing and
+// convergence logic can be checked against the oracle on the build box, which has no GPU.
+// It is compiled by tests/test_hostsim.py into tests/hostsim/_build/ and is never loaded
+// by the llckbdm_amd package (which talks to the HIP library only and fails loudly
+// without it).
+#include <complex>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "kb_eig.hpp"
+#include "kb_svd.hpp"
+
+using namespace kb;
+typedef std::complex<double> zc;
+
+static HostCtx make_ctx(std::vector<char>& arena, size_t bytes) {
+    arena.assign(bytes + KB_RED_BYTES + 64, 0);
+    HostCtx c;
+    c.smem = arena.data();
+    c.smem_bytes = (int)arena.size();
+    return c;
+}
+
+extern "C" {
+
+// A (m x m column-major) -> L (m x m), s (m), R (m x m), A = L diag(s) R^H
+int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_out) {
+    std::vector<cd> A(m * m), Q(m * m), P(m * m), tq(m), tp(m);
+    std::vector<double> d(m), e(m);
+    memcpy(A.data(), A_in, sizeof(cd) * m * m);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, bidiag_scratch_bytes(m, 1, 1) + bdsqr_scratch_bytes(m) + 4 * m);
+    bidiag(ctx, m, A.data(), m, d.data(), e.data(), tq.data(), tp.data());
+    gen_q(ctx, m, A.data(), m, tq.data(), Q.data(), m);
+    gen_p(ctx, m, A.data(), m, tp.data(), P.data(), m);
+    int info = 0;
+    bdsqr(ctx, m, d.data(), e.data(), Q.data(), m, P.data(), m, &info);
+    sort_sv(ctx, m, d.data(), Q.data(), m, P.data(), m, s_out, reinterpret_cast<cd*>(L_out), m,
+            reinterpret_cast<cd*>(R_out), m);
+    return info;
+}
+
+// bidiagonalisation only: returns d, e and explicit Q, P (for stage debugging)
+int hs_bidiag(const double* A_in, int m, double* d, double* e, double* Q_out, double* P_out) {
+    std::vector<cd> A(m * m), tq(m), tp(m);
+    memcpy(A.data(), A_in, sizeof(cd) * m * m);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, bidiag_scratch_bytes(m, 1, 1));
+    bidiag(ctx, m, A.data(), m, d, e, tq.data(), tp.data());
+    gen_q(ctx, m, A.data(), m, tq.data(), reinterpret_cast<cd*>(Q_out), m);
+    gen_p(ctx, m, A.data(), m, tp.data(), reinterpret_cast<cd*>(P_out), m);
+    return 0;
+}
+
+// W (n x n column-major) -> mu (n), P (n x n, column k = eigenvector of mu[k])
+int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
+    std::vector<cd> W(n * n), Qh(n * n), Hc(n * n), Ht(n * n), X(n * n), UT((size_t)n * n), th(n);
+    memcpy(W.data(), W_in, sizeof(cd) * n * n);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n));
+    gehd2(ctx, n, W.data(), n, th.data());
+    gen_qh(ctx, n, W.data(), n, th.data(), Qh.data(), n);
+    hess_copies(ctx, n, W.data(), n, Hc.data(), n, Ht.data(), n);
+    // infinity norm of H (zhsein: hnorm = zlanhs('I'))
+    double hnorm = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double r = 0.0;
+        for (int j = 0; j < n; ++j) r += cabs(Hc[i + (size_t)j * n]);
+        hnorm = r > hnorm ? r : hnorm;
+    }
+    int info = 0, weak = 0;
+    cd* mu = reinterpret_cast<cd*>(mu_out);
+    hqr_eigvals(ctx, n, Hc.data(), n, mu, &info);
+    invit(ctx, n, Ht.data(), n, mu, hnorm, UT.data(), X.data(), n, 1, &weak);
+    // P = Qh * X
+    cd* P = reinterpret_cast<cd*>(P_out);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            cd acc = czero();
+            for (int k = 0; k < n; ++k) cfma(acc, Qh[i + (size_t)k * n], X[k + (size_t)j * n]);
+            P[i + (size_t)j * n] = acc;
+        }
+    return info | (weak ? 4 : 0);
+}
+
+
+// Full single-member pipeline (reference kbdm.py:19-92) with the host context.
+//   signal: N complex; lines: l x 4 row-major (A, T2, F, PH); sv: m; mu: l complex
+int hs_kbdm(const double* signal, int N, int m, int l, int p, double q, double dwell,
+            double* lines, double* sv, double* mu_out) {
+    const cd* c = reinterpret_cast<const cd*>(signal);
+    (void)N;
+    std::vector<double> A((size_t)2 * m * m), L((size_t)2 * m * m), R((size_t)2 * m * m), s(m);
+    cd* Ac = reinterpret_cast<cd*>(A.data());
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) Ac[i + (size_t)j * m] = c[i + j + p - 1];   // U^{p-1}
+    int info = hs_svd(A.data(), m, L.data(), s.data(), R.data());
+    for (int i = 0; i < m; ++i) sv[i] = s[i];
+    const cd* Lc = reinterpret_cast<const cd*>(L.data());
+    const cd* Rc = reinterpret_cast<const cd*>(R.data());
+    std::vector<double> dsqi(l);
+    for (int i = 0; i < l; ++i) dsqi[i] = (q > 0) ? 1.0 / sqrt(s[i] + q * q / s[i]) : 1.0 / sqrt(s[i]);
+    // T1 = Up R_  (m x l),  W = Dsqi L_^H T1 Dsqi (l x l)
+    std::vector<cd> T1((size_t)m * l), W((size_t)l * l);
+    for (int j = 0; j < l; ++j)
+        for (int i = 0; i < m; ++i) {
+            cd acc = czero();
+            for (int k = 0; k < m; ++k) cfma(acc, c[i + k + p], Rc[k + (size_t)j * m]);
+            T1[i + (size_t)j * m] = acc;
+        }
+    for (int j = 0; j < l; ++j)
+        for (int i = 0; i < l; ++i) {
+            cd acc = czero();
+            for (int k = 0; k < m; ++k) cfmac(acc, Lc[k + (size_t)i * m], T1[k + (size_t)j * m]);
+            W[i + (size_t)j * l] = (dsqi[i] * dsqi[j]) * acc;
+        }
+    std::vector<double> P((size_t)2 * l * l);
+    info |= hs_eig(reinterpret_cast<double*>(W.data()), l, mu_out, P.data());
+    const cd* Pc = reinterpret_cast<const cd*>(P.data());
+    const cd* mu = reinterpret_cast<const cd*>(mu_out);
+    // B = R_ Dsqi P (m x l); N_k = b_k^T U0 b_k ; dsq_k = c[:m] . b_k
+    std::vector<cd> B((size_t)m * l);
+    for (int k = 0; k < l; ++k)
+        for (int i = 0; i < m; ++i) {
+            cd acc = czero();
+            for (int j = 0; j < l; ++j) cfma(acc, Rc[i + (size_t)j * m], dsqi[j] * Pc[j + (size_t)k * l]);
+            B[i + (size_t)k * m] = acc;
+        }
+    for (int k = 0; k < l; ++k) {
+        cd nk = czero(), ds = czero();
+        for (int i = 0; i < m; ++i) {
+            cd t = czero();
+            for (int j = 0; j < m; ++j) cfma(t, c[i + j], B[j + (size_t)k * m]);
+            cfma(nk, B[i + (size_t)k * m], t);
+            cfma(ds, c[i], B[i + (size_t)k * m]);
+        }
+        const cd D = cdiv(ds * ds, nk);
+        const double lnabs = log(cabs(mu[k]));
+        lines[4 * k + 0] = cabs(D);
+        lines[4 * k + 1] = -dwell / lnabs;
+        lines[4 * k + 2] = atan2(mu[k].y, mu[k].x) / (2.0 * M_PI * dwell);
+        lines[4 * k + 3] = atan2(D.y, D.x);
+    }
+    return info;
+}
+
+}  // extern "C"
