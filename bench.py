@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""KBDM ensemble throughput on MI355X: `python bench.py --gpus N --steps K --warmup W`.
+
+Metric (BASELINE.json): KBDM solves/sec over an m-range ensemble, N=2048 complex signal.
+Workload at every rank = BASELINE.json configs[1] ("C2"): 16-peak brain-sim signal + seeded
+sigma=1e-3 noise, members m = 100..400 step 2 (151 solves), l = m, p = 1, q = 0.
+One "step" = one pass of the whole pipeline (Hankel -> SVD -> reduced eig -> line lists) over
+that batch, signals already resident in HBM, line lists left in HBM.  With N > 1 every rank
+solves its own ensemble (another noise seed: weak scaling, members are independent) and the
+packed line lists are gathered to every rank with ONE RCCL all_gather inside the timed region.
+
+The JSON line also carries
+  roofline     : the dominant kernel's algorithmic FP64 flops / its HIP-event duration vs the
+                 FP64 matrix peak (flop model: SURVEY.md 8d, stated in DESIGN.md)
+  cpu_baseline : the numpy/scipy oracle (the reference's own LAPACK calls) timed on the host
+                 cores of this box on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix (= vector) peak, datasheet; see DESIGN.md
+HBM_PEAK_GBS = 8000.0
+
+
+def stage_flops(m, l):
+    """Algorithmic real flops per member and pipeline stage (SURVEY.md 8d split of 216 m^3)."""
+    m, l = float(m), float(l)
+    return {
+        "k_hankel": 0.0,
+        "k_svd_fac": (64.0 / 3.0) * m ** 3,          # bidiagonalisation 32/3 + Q,P generation 32/3
+        "k_bdsqr": (84.0 - 64.0 / 3.0) * m ** 3,     # remainder of the 84 m^3 SVD budget
+        "k_gemm<1>": 8.0 * m * m * l,
+        "k_gemm<2>": 8.0 * l * l * m,
+        "k_hess": (56.0 / 3.0) * l ** 3,             # Hessenberg 40/3 + Qh 16/3
+        "k_hqr": (100.0 - 56.0 / 3.0 - 16.0) * l ** 3,
+        "k_invit": 8.0 * l ** 3,
+        "k_gemm<3>": 8.0 * l ** 3,
+        "k_gemm<4>": 8.0 * m * l * l,
+        "k_gemm<5>": 8.0 * m * m * l,
+        "k_epilogue": 0.0,
+    }
+
+
+def _cpu_worker(args):
+    sig, m, dwell = args
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    from oracle import kbdm_oracle as O
+    ll, _ = O.kbdm(sig, dwell, m=int(m), normalizer="gemm")
+    return len(O.filter_samples(ll))
+
+
+def cpu_baseline(sig, ms, dwell):
+    """Oracle (numpy/scipy, one process per core, 1 BLAS thread each) on every 10th member."""
+    import multiprocessing as mp
+    from threadpoolctl import threadpool_limits
+    sample = [int(m) for m in ms[::10]]
+    cores = max(1, min(len(sample), (os.cpu_count() or 1)))
+    with threadpool_limits(1):
+        ctx = mp.get_context("fork")
+        with ctx.Pool(cores) as pool:
+            pool.map(_cpu_worker, [(sig, sample[0], dwell)])          # warm imports
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker, [(sig, m, dwell) for m in sample], chunksize=1)
+            dt = time.perf_counter() - t0
+    return {"value": len(sample) / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"every 10th member of C2 (m={sample[0]}..{sample[-1]}, {len(sample)} solves), "
+                      f"numpy/scipy oracle (zgesdd+zgeev), one process per core, 1 BLAS thread each, "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3small"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1 or args.gpus > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        try:
+            import torch
+        except Exception:
+            torch = None
+
+    from llckbdm_amd import datasets
+    from llckbdm_amd.engine import Engine
+
+    eng = Engine(local_rank)
+    dwell = datasets.DWELL
+    if args.workload == "C2":
+        sigs, sig_idx, ms = datasets.config2(seed=rank)
+        wname = "C2: N=2048, 16 peaks + sigma=1e-3 noise, m=100..400:2 (151 members), l=m, p=1, q=0"
+    else:
+        sigs, sig_idx, ms = datasets.config3(count=64, m=512, seed0=1000 * rank)
+        wname = "C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512"
+    plan = eng.plan(sigs.shape[0], sigs.shape[1], sig_idx, ms, ms, p=1, q=0.0, dwell=dwell)
+    plan.upload(sigs)
+    units = len(ms)
+
+    gather_buf = local_buf = None
+    if dist is not None:
+        local_buf = torch.empty((plan.total_lines, 4), dtype=torch.float64, device="cuda")
+        gather_buf = torch.empty((world * plan.total_lines, 4), dtype=torch.float64, device="cuda")
+
+    def sync_all():
+        plan.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def step():
+        plan.execute(sync=False)
+        if dist is not None:
+            plan.copy_lines_to_device(local_buf.data_ptr(), local_buf.numel() * 8)   # syncs the plan stream
+            dist.all_gather_into_tensor(gather_buf, local_buf)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if dist is None:
+            # per-stage HIP-event times (waits for the stream; the next step could not overlap anyway:
+            # it reuses the same workspace)
+            for k, v in plan.stage_ms().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        for k, v in plan.stage_ms().items():
+            stage_acc[k] = v * args.steps
+
+    res = plan.download()
+    ok = int((res.status == 0).sum())
+
+    if rank == 0:
+        value = world * units * args.steps / elapsed
+        stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+        fl = {}
+        for m in ms:
+            for k, v in stage_flops(m, m).items():
+                fl[k] = fl.get(k, 0.0) + v
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                    "avg_ms": stage_ms[dom], "algorithmic_flops_per_launch": fl[dom]}
+        total_fl = sum(fl.values())
+        out = {
+            "metric": "KBDM solves/sec over m-range ensemble, N=2048 complex signal",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
+            "config": {"workload": wname, "members_per_gpu": units, "parallelism": f"ensemble-sharded x{world}",
+                       "collective": "one all_gather of packed line lists (RCCL)" if world > 1 else "none"},
+            "roofline": roofline,
+            "pipeline_tflops": total_fl * args.steps * world / elapsed / 1e12,
+            "stage_ms": stage_ms,
+            "members_ok": ok,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sigs[0], ms, dwell) if args.workload == "C2" else None
+            except Exception as e:   # the baseline is informational; never lose the GPU number over it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+/*
+ * kbdm_hip.h - C ABI of libkbdm_hip.so: the MI355X (gfx950) KBDM ensemble solver.
+ *
+ * The reference (danilomendesdias/llckbdm) is pure Python and has no FFI layer; its hot
+ * path is the loop llckbdm/sampling.py:52-70 calling llckbdm/kbdm.py:19-92 once per
+ * ensemble member.  This library replaces exactly that loop with one batched HIP
+ * pipeline.  Everything here is plain C: pointers, sizes, error codes.  No exceptions
+ * cross the boundary; every function returns 0 on success or a negative KBDM_E_* code
+ * (kbdm_last_error() gives the text).  The Python side (llckbdm_amd/_lib.py) binds these
+ * symbols with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Data conventions
+ *   complex128  = two consecutive doubles (re, im), as numpy complex128.
+ *   signals     : S x N complex128, row-major (one time signal per row).
+ *   items       : ensemble members; item i solves signal sig_idx[i] with Krylov size m[i]
+ *                 and retained rank l[i] (1 <= l[i] <= m[i], 2*m[i] + p - 1 <= N).
+ *   lines       : concatenated per item, row-major (l_i x 4) doubles in the reference's
+ *                 column order (amplitude, T2, frequency, phase)   [kbdm.py:88-90]
+ *   sv          : concatenated per item, m_i doubles, descending   [KbdmInfo.singular_values]
+ *   mu          : concatenated per item, l_i complex128 eigenvalues [kbdm.py:192]
+ *   keep        : concatenated per item, l_i bytes: 1 iff A > 1e-6 and T2 > 0
+ *                 (filter_samples, sampling.py:75-97)
+ *   status      : per item bit mask, 0 = ok (KBDM_STAT_*).
+ *   Row order inside one item's line list is the order in which this library's
+ *   eigen-solver delivers eigenvalues; like LAPACK zgeev's order in the reference it
+ *   carries no meaning.
+ */
+#ifndef KBDM_HIP_H
+#define KBDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KBDM_ABI_VERSION 1
+
+#define KBDM_OK 0
+#define KBDM_E_INVALID (-1)   /* bad argument (sizes, null pointers, m/l/p constraint) */
+#define KBDM_E_HIP (-2)       /* a HIP runtime call failed                            */
+#define KBDM_E_NOMEM (-3)     /* workspace does not fit                               */
+#define KBDM_E_NODEVICE (-4)  /* no gfx950 device visible                             */
+
+#define KBDM_STAT_SVD_NOCONV 1
+#define KBDM_STAT_EIG_NOCONV 2
+#define KBDM_STAT_INVIT_WEAK 4
+
+/* number of per-stage timers reported by kbdm_plan_stage_ms */
+#define KBDM_NSTAGES 12
+
+typedef struct kbdm_ctx kbdm_ctx;
+typedef struct kbdm_plan kbdm_plan;
+
+int kbdm_abi_version(void);
+int kbdm_device_count(void);
+const char* kbdm_last_error(void);
+
+/* One context per process and GPU: device selection, stream, module attributes. */
+int kbdm_ctx_create(int device, kbdm_ctx** out);
+int kbdm_ctx_destroy(kbdm_ctx* ctx);
+
+/* A plan fixes the batch geometry (replaces the arguments of sample_kbdm,
+ * sampling.py:8: data/m_range/p/l/q, for many signals at once) and owns the device
+ * workspace.  Items may have different m and l. */
+int kbdm_plan_create(kbdm_ctx* ctx, int S, int N, int B, const int32_t* sig_idx, const int32_t* m,
+                     const int32_t* l, int p, double q, double dwell, kbdm_plan** out);
+int kbdm_plan_destroy(kbdm_plan* plan);
+int64_t kbdm_plan_total_lines(const kbdm_plan* plan); /* sum of l_i */
+int64_t kbdm_plan_total_sv(const kbdm_plan* plan);    /* sum of m_i */
+/* per-item offsets (B+1 entries each) into lines/keep/mu (units: lines) and sv (units: values) */
+int kbdm_plan_offsets(const kbdm_plan* plan, int64_t* line_off, int64_t* sv_off);
+
+int kbdm_plan_upload(kbdm_plan* plan, const double* signals_host); /* S*N complex128, H2D   */
+int kbdm_plan_execute(kbdm_plan* plan);                            /* enqueue every kernel  */
+int kbdm_plan_sync(kbdm_plan* plan);                               /* wait for the stream   */
+int kbdm_plan_download(kbdm_plan* plan, double* lines, double* sv, double* mu, uint8_t* keep,
+                       int32_t* status);                           /* D2H (null = skip)     */
+/* device-resident outputs (for a collective over xGMI without a host bounce) */
+void* kbdm_plan_lines_device(kbdm_plan* plan);
+void* kbdm_plan_sv_device(kbdm_plan* plan);
+/* device-to-device copy of the packed lines (total_lines x 4 doubles) into a caller-owned
+ * device buffer (e.g. a torch tensor that RCCL gathers); synchronous on the plan's stream */
+int kbdm_plan_copy_lines_device(kbdm_plan* plan, void* dst_device, int64_t dst_bytes);
+/* elapsed ms of each pipeline stage in the last execute (HIP events on the plan's stream);
+ * also returns the kernel names through kbdm_stage_name */
+int kbdm_plan_stage_ms(kbdm_plan* plan, float* ms, int n);
+const char* kbdm_stage_name(int stage);
+
+/* One-shot: plan + upload + execute + download.  line_off/sv_off (B+1) are outputs. */
+int kbdm_solve_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B,
+                     const int32_t* sig_idx, const int32_t* m, const int32_t* l, int p, double q,
+                     double dwell, double* lines, double* sv, double* mu, uint8_t* keep,
+                     int32_t* status);
+
+/* ---- stage entry points (parity tests of SURVEY.md 8a rows a3, a4, a7) ---------------- */
+/* Hankel assembly, reference kbdm.py:95-130: for item i writes U0, U^{p-1}, U^p, each
+ * m_i x m_i ROW-major (numpy C order), items concatenated.  Any output may be null. */
+int kbdm_hankel_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B,
+                      const int32_t* sig_idx, const int32_t* m, int p, double* U0, double* Up1,
+                      double* Up);
+/* Full SVD, reference kbdm.py:166: A_i (m_i x m_i, row-major, concatenated) ->
+ * L_i (row-major), s_i, R_i (row-major) with A = L diag(s) R^H. */
+int kbdm_svd_batch(kbdm_ctx* ctx, const double* A, int B, const int32_t* m, double* L, double* s,
+                   double* R, int32_t* status);
+/* Eigen-decomposition, reference kbdm.py:192: W_i (n_i x n_i row-major) -> mu_i, P_i
+ * (row-major, column k = right eigenvector of mu_k, arbitrary scale). */
+int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, double* mu, double* P,
+                   int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBDM_HIP_H */

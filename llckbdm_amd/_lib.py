@@ -1,0 +1,82 @@
+"""ctypes binding of libkbdm_hip.so (C ABI: include/kbdm_hip.h).
+
+Fails loudly when the HIP library is missing or no GPU is visible: this package has no
+CPU compute path (the numpy oracle under ``oracle/`` is test infrastructure and is never
+imported from here).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libkbdm_hip.so")
+
+KBDM_ABI_VERSION = 1
+KBDM_NSTAGES = 12
+STAT_SVD_NOCONV, STAT_EIG_NOCONV, STAT_INVIT_WEAK = 1, 2, 4
+
+# every symbol include/kbdm_hip.h declares: (restype, argtypes)
+_P = c_void_p
+SYMBOLS = {
+    "kbdm_abi_version": (c_int, []),
+    "kbdm_device_count": (c_int, []),
+    "kbdm_last_error": (c_char_p, []),
+    "kbdm_ctx_create": (c_int, [c_int, POINTER(_P)]),
+    "kbdm_ctx_destroy": (c_int, [_P]),
+    "kbdm_plan_create": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_double, c_double, POINTER(_P)]),
+    "kbdm_plan_destroy": (c_int, [_P]),
+    "kbdm_plan_total_lines": (c_int64, [_P]),
+    "kbdm_plan_total_sv": (c_int64, [_P]),
+    "kbdm_plan_offsets": (c_int, [_P, _P, _P]),
+    "kbdm_plan_upload": (c_int, [_P, _P]),
+    "kbdm_plan_execute": (c_int, [_P]),
+    "kbdm_plan_sync": (c_int, [_P]),
+    "kbdm_plan_download": (c_int, [_P, _P, _P, _P, _P, _P]),
+    "kbdm_plan_lines_device": (_P, [_P]),
+    "kbdm_plan_sv_device": (_P, [_P]),
+    "kbdm_plan_copy_lines_device": (c_int, [_P, _P, c_int64]),
+    "kbdm_plan_stage_ms": (c_int, [_P, _P, c_int]),
+    "kbdm_stage_name": (c_char_p, [c_int]),
+    "kbdm_solve_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_double, c_double,
+                                 _P, _P, _P, _P, _P]),
+    "kbdm_hankel_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
+    "kbdm_svd_batch": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P]),
+    "kbdm_eig_batch": (c_int, [_P, _P, c_int, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class KbdmHipError(RuntimeError):
+    """A libkbdm_hip.so call returned a negative KBDM_E_* code."""
+
+
+def load():
+    """Load the shared library and bind every declared symbol (no GPU call is made)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m llckbdm_amd.build` (hipcc, gfx950). "
+            "llckbdm_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError here = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kbdm_abi_version() != KBDM_ABI_VERSION:
+        raise ImportError(f"libkbdm_hip.so ABI {lib.kbdm_abi_version()} != expected {KBDM_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().kbdm_last_error()
+        raise KbdmHipError(f"libkbdm_hip error {code}: {msg.decode() if msg else ''}")
+
+
+def ptr(arr):
+    """Raw pointer of a C-contiguous numpy array (or None)."""
+    return None if arr is None else arr.ctypes.data_as(c_void_p)

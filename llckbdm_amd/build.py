@@ -1,0 +1,36 @@
+"""Build libkbdm_hip.so (gfx950) in-tree with hipcc.  ``python -m llckbdm_amd.build``."""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libkbdm_hip.so")
+SOURCES = ["kbdm_hip.hip"]
+HEADERS = ["kbdm_kernels.hpp", "kbdm_device.h", "kb_complex.hpp", "kb_ctx.hpp", "kb_svd.hpp", "kb_eig.hpp",
+           os.path.join("..", "..", "include", "kbdm_hip.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into llckbdm_amd/libkbdm_hip.so."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -81,12 +81,4 @@ constexpr double KB_EPS = 1.1102230246251565e-16;    // 2^-53  (LAPACK dlamch('E
 constexpr double KB_ULP = 2.2204460492503131e-16;    // 2^-52  (LAPACK dlamch('P'))
 constexpr double KB_SAFMIN = 2.2250738585072014e-308;
 
-// status bits reported per ensemble member
-enum : int {
-    KB_STAT_OK = 0,
-    KB_STAT_SVD_NOCONV = 1,
-    KB_STAT_EIG_NOCONV = 2,
-    KB_STAT_INVIT_WEAK = 4,   // an eigenvector did not reach the growth criterion
-};
-
 }  // namespace kb

@@ -1,0 +1,613 @@
+// libkbdm_hip.so - host side of the C ABI declared in include/kbdm_hip.h.
+// Plans the batch (sort by cost, carve the workspace, chunk if it would not fit), enqueues
+// the kernels of kbdm_kernels.hpp on one HIP stream and moves results.  No CPU compute path
+// exists here: without a gfx950 device every entry point fails with KBDM_E_NODEVICE/HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/kbdm_hip.h"
+#include "kbdm_kernels.hpp"
+
+using namespace kb;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail(KBDM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+int env_int(const char* name, int def) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : def;
+}
+
+constexpr int LDS_MAX = 160 * 1024;
+constexpr int UT_WAVES_MAX = 8;
+
+const char* kStageNames[KBDM_NSTAGES] = {"k_hankel", "k_svd_fac", "k_bdsqr",  "k_gemm<1>", "k_gemm<2>", "k_hess",
+                                         "k_hqr",    "k_invit",   "k_gemm<3>", "k_gemm<4>", "k_gemm<5>", "k_epilogue"};
+
+}  // namespace
+
+struct kbdm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nt_fac = 1024;    // threads per workgroup: bidiagonalisation / Hessenberg kernels
+    int nt_bdsqr = 1024;
+    int nt_hqr = 256;
+    int nt_invit = 512;
+    double ws_budget_gib = 96.0;
+};
+
+struct Chunk {
+    int first = 0, count = 0;   // range in sorted order
+    int mmax = 0, lmax = 0;
+    std::vector<hipEvent_t> ev;
+};
+
+struct kbdm_plan {
+    kbdm_ctx* ctx = nullptr;
+    int S = 0, N = 0, B = 0, p = 1;
+    double q = 0.0, dwell = 0.0;
+    std::vector<KbItem> items;     // caller order
+    std::vector<int> perm;         // sorted position -> item index (descending cost)
+    std::vector<Chunk> chunks;
+    std::vector<int64_t> line_off, sv_off;
+    int64_t total_lines = 0, total_sv = 0;
+    size_t arena_elems = 0, varena_elems = 0;
+    cd* d_signals = nullptr;
+    KbItem* d_items = nullptr;
+    int* d_perm = nullptr;
+    cd* d_arena = nullptr;
+    double* d_varena = nullptr;
+    double* d_lines = nullptr;
+    double* d_sv = nullptr;
+    cd* d_mu = nullptr;
+    unsigned char* d_keep = nullptr;
+    int* d_status = nullptr;
+    float stage_ms[KBDM_NSTAGES] = {0};
+    bool timed = false;
+};
+
+namespace {
+
+size_t item_arena_elems(int m, int l, int ut_waves) {
+    const size_t M = (size_t)m * m, L2 = (size_t)l * l;
+    // A, Q, P, R, H : m*m each;  T : l*l;  UT : ut_waves * l*l
+    return 5 * M + L2 + (size_t)ut_waves * L2;
+}
+
+int set_lds_attr() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svd_fac), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    return KBDM_OK;
+}
+
+// Build items / order / chunks / device descriptors.  mode: 0 = full pipeline,
+// 1 = stage API (dense m*m host layouts, hk_off).
+int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const int32_t* l) {
+    kbdm_ctx* ctx = pl->ctx;
+    const int B = pl->B;
+    pl->items.resize(B);
+    pl->line_off.assign(B + 1, 0);
+    pl->sv_off.assign(B + 1, 0);
+    const int ut_waves = std::min(UT_WAVES_MAX, ctx->nt_invit / 64);
+    int64_t hk = 0;
+    for (int i = 0; i < B; ++i) {
+        KbItem& it = pl->items[i];
+        memset(&it, 0, sizeof(it));
+        it.m = m[i];
+        it.l = l ? l[i] : m[i];
+        it.sig = sig_idx ? sig_idx[i] : 0;
+        it.ut_waves = ut_waves;
+        it.q = pl->q;
+        if (it.m < 1 || it.l < 1 || it.l > it.m) return fail(KBDM_E_INVALID, "item with invalid m/l");
+        if (pl->N > 0 && (2 * it.m + pl->p - 1 > pl->N || it.sig < 0 || it.sig >= pl->S))
+            return fail(KBDM_E_INVALID, "m can't be greater than (n + 1 - p)/2 / bad signal index");
+        pl->line_off[i + 1] = pl->line_off[i] + it.l;
+        pl->sv_off[i + 1] = pl->sv_off[i] + it.m;
+        it.line_off = pl->line_off[i];
+        it.sv_off = pl->sv_off[i];
+        it.hk_off = hk;
+        hk += (int64_t)it.m * it.m;
+    }
+    pl->total_lines = pl->line_off[B];
+    pl->total_sv = pl->sv_off[B];
+    // order by descending cost (~m^3): the longest-running workgroups start first
+    pl->perm.resize(B);
+    std::iota(pl->perm.begin(), pl->perm.end(), 0);
+    std::stable_sort(pl->perm.begin(), pl->perm.end(),
+                     [&](int a, int b) { return pl->items[a].m > pl->items[b].m; });
+    // chunks: consecutive sorted items whose workspace fits the budget
+    const size_t budget = (size_t)(ctx->ws_budget_gib * 1024.0 * 1024.0 * 1024.0) / sizeof(cd);
+    pl->chunks.clear();
+    size_t used = 0, vused = 0;
+    Chunk cur;
+    pl->arena_elems = 0;
+    pl->varena_elems = 0;
+    for (int pos = 0; pos < B; ++pos) {
+        KbItem& it = pl->items[pl->perm[pos]];
+        const size_t need = item_arena_elems(it.m, it.l, it.ut_waves);
+        if (need > budget) return fail(KBDM_E_NOMEM, "one item exceeds the workspace budget");
+        if (cur.count > 0 && used + need > budget) {
+            pl->chunks.push_back(cur);
+            cur = Chunk();
+            cur.first = pos;
+            used = 0;
+            vused = 0;
+        }
+        const size_t M = (size_t)it.m * it.m, L2 = (size_t)it.l * it.l;
+        size_t o = used;
+        it.off[KB_BUF_A] = o; o += M;
+        it.off[KB_BUF_Q] = o; o += M;
+        it.off[KB_BUF_P] = o; o += M;
+        it.off[KB_BUF_R] = o; o += M;
+        it.off[KB_BUF_H] = o; o += M;
+        it.off[KB_BUF_T] = o; o += L2;
+        it.off[KB_BUF_UT] = o; o += (size_t)it.ut_waves * L2;
+        used = o;
+        it.vstride = (it.m + 1) & ~1;
+        it.voff = (long long)vused;
+        vused += (size_t)KB_V_SLOTS * it.vstride;
+        cur.count++;
+        cur.mmax = std::max(cur.mmax, it.m);
+        cur.lmax = std::max(cur.lmax, it.l);
+        pl->arena_elems = std::max(pl->arena_elems, used);
+        pl->varena_elems = std::max(pl->varena_elems, vused);
+    }
+    if (cur.count > 0) pl->chunks.push_back(cur);
+    return KBDM_OK;
+}
+
+int plan_alloc(kbdm_plan* pl) {
+    const int B = pl->B;
+    HIPCHK(hipMalloc(&pl->d_items, sizeof(KbItem) * B));
+    HIPCHK(hipMalloc(&pl->d_perm, sizeof(int) * B));
+    HIPCHK(hipMemcpy(pl->d_items, pl->items.data(), sizeof(KbItem) * B, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pl->d_perm, pl->perm.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&pl->d_arena, sizeof(cd) * std::max<size_t>(pl->arena_elems, 1)));
+    HIPCHK(hipMalloc(&pl->d_varena, sizeof(double) * std::max<size_t>(pl->varena_elems, 1)));
+    HIPCHK(hipMalloc(&pl->d_lines, sizeof(double) * 4 * std::max<int64_t>(pl->total_lines, 1)));
+    HIPCHK(hipMalloc(&pl->d_sv, sizeof(double) * std::max<int64_t>(pl->total_sv, 1)));
+    HIPCHK(hipMalloc(&pl->d_mu, sizeof(cd) * std::max<int64_t>(pl->total_lines, 1)));
+    HIPCHK(hipMalloc(&pl->d_keep, std::max<int64_t>(pl->total_lines, 1)));
+    HIPCHK(hipMalloc(&pl->d_status, sizeof(int) * B));
+    if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
+    return KBDM_OK;
+}
+
+struct StageTimer {
+    kbdm_plan* pl;
+    Chunk* ch;
+    int idx = 0;
+    int init() {
+        if (ch->ev.empty()) {
+            ch->ev.resize(KBDM_NSTAGES + 1);
+            for (auto& e : ch->ev) HIPCHK(hipEventCreate(&e));
+        }
+        HIPCHK(hipEventRecord(ch->ev[0], pl->ctx->stream));
+        idx = 1;
+        return KBDM_OK;
+    }
+    int mark() {
+        HIPCHK(hipEventRecord(ch->ev[idx], pl->ctx->stream));
+        idx++;
+        return KBDM_OK;
+    }
+};
+
+int smem_fac(int n, int nt) { return KB_RED_BYTES + bidiag_scratch_bytes(n, nt / 64, 64); }
+
+int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
+    kbdm_ctx* ctx = pl->ctx;
+    hipStream_t st = ctx->stream;
+    const int* perm = pl->d_perm + ch.first;
+    {
+        const int sm = smem_fac(ch.mmax, ctx->nt_fac);
+        if (sm > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the bidiagonalisation scratch");
+        hipLaunchKernelGGL(k_svd_fac, dim3(ch.count), dim3(ctx->nt_fac), sm, st, pl->d_items, perm, pl->d_arena,
+                           pl->d_varena, sm);
+        if (tm) { int r = tm->mark(); if (r) return r; }
+    }
+    {
+        const int sm = KB_RED_BYTES + std::max(bdsqr_scratch_bytes(ch.mmax), 4 * ch.mmax + 64);
+        if (sm > LDS_MAX - 64) return fail(KBDM_E_NOMEM, "m too large for the bidiagonal QR scratch");
+        hipLaunchKernelGGL(k_bdsqr, dim3(ch.count), dim3(ctx->nt_bdsqr), sm, st, pl->d_items, perm, pl->d_arena,
+                           pl->d_varena, pl->d_sv, pl->d_status, sm);
+        if (tm) { int r = tm->mark(); if (r) return r; }
+    }
+    HIPCHK(hipGetLastError());
+    return KBDM_OK;
+}
+
+int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
+    kbdm_ctx* ctx = pl->ctx;
+    hipStream_t st = ctx->stream;
+    const int* perm = pl->d_perm + ch.first;
+    {
+        const int sm = KB_RED_BYTES + gehd2_scratch_bytes(ch.lmax, ctx->nt_fac / 64, 64);
+        if (sm > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg scratch");
+        hipLaunchKernelGGL(k_hess, dim3(ch.count), dim3(ctx->nt_fac), sm, st, pl->d_items, perm, pl->d_arena,
+                           pl->d_varena, sm);
+        if (tm) { int r = tm->mark(); if (r) return r; }
+    }
+    {
+        const int sm = KB_RED_BYTES + 64;
+        hipLaunchKernelGGL(k_hqr, dim3(ch.count), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
+                           pl->d_varena, pl->d_mu, pl->d_status, sm);
+        if (tm) { int r = tm->mark(); if (r) return r; }
+    }
+    {
+        const int per = invit_scratch_bytes_per_wave(ch.lmax);
+        int nw = std::min(ctx->nt_invit / 64, UT_WAVES_MAX);
+        nw = std::min(nw, (LDS_MAX - 64 - KB_RED_BYTES) / per);
+        if (nw < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
+        const int sm = KB_RED_BYTES + nw * per;
+        hipLaunchKernelGGL(k_invit, dim3(ch.count), dim3(ctx->nt_invit), sm, st, pl->d_items, perm, pl->d_arena,
+                           pl->d_varena, pl->d_mu, pl->d_status, sm);
+        if (tm) { int r = tm->mark(); if (r) return r; }
+    }
+    HIPCHK(hipGetLastError());
+    return KBDM_OK;
+}
+
+template <int STAGE>
+void launch_gemm(kbdm_plan* pl, Chunk& ch, int Mmax, int Nmax) {
+    const int* perm = pl->d_perm + ch.first;
+    dim3 grid((Mmax + GT - 1) / GT, (Nmax + GT - 1) / GT, ch.count);
+    hipLaunchKernelGGL(k_gemm<STAGE>, grid, dim3(256), 0, pl->ctx->stream, pl->d_items, perm, pl->d_signals, pl->N,
+                       pl->p, pl->d_arena, pl->d_varena);
+}
+
+}  // namespace
+
+extern "C" {
+
+int kbdm_abi_version(void) { return KBDM_ABI_VERSION; }
+
+const char* kbdm_last_error(void) { return g_err.c_str(); }
+
+int kbdm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* kbdm_stage_name(int stage) {
+    return (stage >= 0 && stage < KBDM_NSTAGES) ? kStageNames[stage] : "";
+}
+
+int kbdm_ctx_create(int device, kbdm_ctx** out) {
+    if (!out) return fail(KBDM_E_INVALID, "null out pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KBDM_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(KBDM_E_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    kbdm_ctx* c = new kbdm_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->nt_fac = env_int("KBDM_NT_FAC", c->nt_fac);
+    c->nt_bdsqr = env_int("KBDM_NT_BDSQR", c->nt_bdsqr);
+    c->nt_hqr = env_int("KBDM_NT_HQR", c->nt_hqr);
+    c->nt_invit = env_int("KBDM_NT_INVIT", c->nt_invit);
+    if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
+    int r = set_lds_attr();
+    if (r) { delete c; return r; }
+    *out = c;
+    return KBDM_OK;
+}
+
+int kbdm_ctx_destroy(kbdm_ctx* ctx) {
+    if (!ctx) return KBDM_OK;
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return KBDM_OK;
+}
+
+int kbdm_plan_create(kbdm_ctx* ctx, int S, int N, int B, const int32_t* sig_idx, const int32_t* m,
+                     const int32_t* l, int p, double q, double dwell, kbdm_plan** out) {
+    if (!ctx || !out || !m || B < 0 || S < 1 || N < 1 || p < 1) return fail(KBDM_E_INVALID, "bad plan arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    kbdm_plan* pl = new kbdm_plan();
+    pl->ctx = ctx; pl->S = S; pl->N = N; pl->B = B; pl->p = p; pl->q = q; pl->dwell = dwell;
+    int r = plan_build(pl, sig_idx, m, l);
+    if (!r) r = plan_alloc(pl);
+    if (r) { kbdm_plan_destroy(pl); return r; }
+    *out = pl;
+    return KBDM_OK;
+}
+
+int kbdm_plan_destroy(kbdm_plan* pl) {
+    if (!pl) return KBDM_OK;
+    hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
+    hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
+    hipFree(pl->d_keep); hipFree(pl->d_status);
+    for (auto& ch : pl->chunks)
+        for (auto& e : ch.ev) hipEventDestroy(e);
+    delete pl;
+    return KBDM_OK;
+}
+
+int64_t kbdm_plan_total_lines(const kbdm_plan* pl) { return pl ? pl->total_lines : 0; }
+int64_t kbdm_plan_total_sv(const kbdm_plan* pl) { return pl ? pl->total_sv : 0; }
+
+int kbdm_plan_offsets(const kbdm_plan* pl, int64_t* line_off, int64_t* sv_off) {
+    if (!pl) return fail(KBDM_E_INVALID, "null plan");
+    if (line_off) memcpy(line_off, pl->line_off.data(), sizeof(int64_t) * (pl->B + 1));
+    if (sv_off) memcpy(sv_off, pl->sv_off.data(), sizeof(int64_t) * (pl->B + 1));
+    return KBDM_OK;
+}
+
+int kbdm_plan_upload(kbdm_plan* pl, const double* signals_host) {
+    if (!pl || !signals_host) return fail(KBDM_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipMemcpyAsync(pl->d_signals, signals_host, sizeof(cd) * (size_t)pl->S * pl->N, hipMemcpyHostToDevice,
+                          pl->ctx->stream));
+    HIPCHK(hipStreamSynchronize(pl->ctx->stream));
+    return KBDM_OK;
+}
+
+int kbdm_plan_execute(kbdm_plan* pl) {
+    if (!pl) return fail(KBDM_E_INVALID, "null plan");
+    if (pl->B == 0) return KBDM_OK;
+    kbdm_ctx* ctx = pl->ctx;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(pl->d_status, 0, sizeof(int) * pl->B, st));
+    for (auto& ch : pl->chunks) {
+        StageTimer tm{pl, &ch};
+        int r = tm.init();
+        if (r) return r;
+        const int* perm = pl->d_perm + ch.first;
+        {   // K1: U^{p-1} into the SVD work buffer
+            HankelOut o0{pl->d_arena, pl->p - 1, KB_BUF_A, 1};
+            HankelOut none{nullptr, 0, 0, 0};
+            const int tiles = (ch.mmax + HK_TILE - 1) / HK_TILE;
+            hipLaunchKernelGGL(k_hankel, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
+                               pl->d_signals, pl->N, 1, o0, none, none);
+            if ((r = tm.mark())) return r;
+        }
+        if ((r = launch_svd(pl, ch, &tm))) return r;
+        launch_gemm<1>(pl, ch, ch.mmax, ch.lmax);
+        if ((r = tm.mark())) return r;
+        launch_gemm<2>(pl, ch, ch.lmax, ch.lmax);
+        if ((r = tm.mark())) return r;
+        if ((r = launch_eig(pl, ch, &tm))) return r;
+        launch_gemm<3>(pl, ch, ch.lmax, ch.lmax);
+        if ((r = tm.mark())) return r;
+        launch_gemm<4>(pl, ch, ch.mmax, ch.lmax);
+        if ((r = tm.mark())) return r;
+        launch_gemm<5>(pl, ch, ch.mmax, ch.lmax);
+        if ((r = tm.mark())) return r;
+        {
+            const int wpb = 4;
+            dim3 grid((ch.lmax + wpb - 1) / wpb, ch.count);
+            hipLaunchKernelGGL(k_epilogue, grid, dim3(64 * wpb), 0, st, pl->d_items, perm, pl->d_signals, pl->N,
+                               pl->d_arena, pl->d_mu, pl->dwell, pl->d_lines, pl->d_keep);
+            if ((r = tm.mark())) return r;
+        }
+        HIPCHK(hipGetLastError());
+    }
+    pl->timed = true;
+    return KBDM_OK;
+}
+
+int kbdm_plan_sync(kbdm_plan* pl) {
+    if (!pl) return fail(KBDM_E_INVALID, "null plan");
+    HIPCHK(hipStreamSynchronize(pl->ctx->stream));
+    return KBDM_OK;
+}
+
+int kbdm_plan_stage_ms(kbdm_plan* pl, float* ms, int n) {
+    if (!pl || !ms) return fail(KBDM_E_INVALID, "null argument");
+    HIPCHK(hipStreamSynchronize(pl->ctx->stream));
+    for (int s = 0; s < KBDM_NSTAGES; ++s) pl->stage_ms[s] = 0.f;
+    if (pl->timed)
+        for (auto& ch : pl->chunks) {
+            if (ch.ev.empty()) continue;
+            for (int s = 0; s < KBDM_NSTAGES; ++s) {
+                float t = 0.f;
+                HIPCHK(hipEventElapsedTime(&t, ch.ev[s], ch.ev[s + 1]));
+                pl->stage_ms[s] += t;
+            }
+        }
+    for (int s = 0; s < n && s < KBDM_NSTAGES; ++s) ms[s] = pl->stage_ms[s];
+    return KBDM_OK;
+}
+
+int kbdm_plan_download(kbdm_plan* pl, double* lines, double* sv, double* mu, uint8_t* keep, int32_t* status) {
+    if (!pl) return fail(KBDM_E_INVALID, "null plan");
+    hipStream_t st = pl->ctx->stream;
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    if (lines && pl->total_lines) HIPCHK(hipMemcpyAsync(lines, pl->d_lines, sizeof(double) * 4 * pl->total_lines, hipMemcpyDeviceToHost, st));
+    if (sv && pl->total_sv) HIPCHK(hipMemcpyAsync(sv, pl->d_sv, sizeof(double) * pl->total_sv, hipMemcpyDeviceToHost, st));
+    if (mu && pl->total_lines) HIPCHK(hipMemcpyAsync(mu, pl->d_mu, sizeof(cd) * pl->total_lines, hipMemcpyDeviceToHost, st));
+    if (keep && pl->total_lines) HIPCHK(hipMemcpyAsync(keep, pl->d_keep, pl->total_lines, hipMemcpyDeviceToHost, st));
+    if (status && pl->B) HIPCHK(hipMemcpyAsync(status, pl->d_status, sizeof(int) * pl->B, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return KBDM_OK;
+}
+
+void* kbdm_plan_lines_device(kbdm_plan* pl) { return pl ? pl->d_lines : nullptr; }
+void* kbdm_plan_sv_device(kbdm_plan* pl) { return pl ? pl->d_sv : nullptr; }
+
+int kbdm_plan_copy_lines_device(kbdm_plan* pl, void* dst, int64_t dst_bytes) {
+    if (!pl || !dst) return fail(KBDM_E_INVALID, "null argument");
+    const int64_t need = (int64_t)sizeof(double) * 4 * pl->total_lines;
+    if (dst_bytes < need) return fail(KBDM_E_INVALID, "destination too small");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, pl->d_lines, need, hipMemcpyDeviceToDevice, pl->ctx->stream));
+    HIPCHK(hipStreamSynchronize(pl->ctx->stream));
+    return KBDM_OK;
+}
+
+int kbdm_solve_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B, const int32_t* sig_idx,
+                     const int32_t* m, const int32_t* l, int p, double q, double dwell, double* lines,
+                     double* sv, double* mu, uint8_t* keep, int32_t* status) {
+    kbdm_plan* pl = nullptr;
+    int r = kbdm_plan_create(ctx, S, N, B, sig_idx, m, l, p, q, dwell, &pl);
+    if (r) return r;
+    r = kbdm_plan_upload(pl, signals);
+    if (!r) r = kbdm_plan_execute(pl);
+    if (!r) r = kbdm_plan_download(pl, lines, sv, mu, keep, status);
+    kbdm_plan_destroy(pl);
+    return r;
+}
+
+// ---------------------------------------------------------------- stage entry points
+int kbdm_hankel_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B, const int32_t* sig_idx,
+                      const int32_t* m, int p, double* U0, double* Up1, double* Up) {
+    if (!ctx || !signals || !m) return fail(KBDM_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    kbdm_plan pl;
+    pl.ctx = ctx; pl.S = S; pl.N = N; pl.B = B; pl.p = p;
+    // Hankel only needs indices up to 2m-2+p <= N-1
+    int r = plan_build(&pl, sig_idx, m, nullptr);
+    if (r) return r;
+    size_t tot = 0;
+    int mmax = 0;
+    for (auto& it : pl.items) { tot += (size_t)it.m * it.m; mmax = std::max(mmax, it.m); }
+    cd *d_sig = nullptr, *d_out[3] = {nullptr, nullptr, nullptr};
+    KbItem* d_items = nullptr;
+    double* host_out[3] = {U0, Up1, Up};
+    const int shifts[3] = {0, p - 1, p};
+    HIPCHK(hipMalloc(&d_sig, sizeof(cd) * (size_t)S * N));
+    HIPCHK(hipMalloc(&d_items, sizeof(KbItem) * B));
+    HIPCHK(hipMemcpy(d_sig, signals, sizeof(cd) * (size_t)S * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_items, pl.items.data(), sizeof(KbItem) * B, hipMemcpyHostToDevice));
+    HankelOut o[3];
+    int nout = 0;
+    int which[3];
+    for (int k = 0; k < 3; ++k)
+        if (host_out[k]) {
+            HIPCHK(hipMalloc(&d_out[k], sizeof(cd) * std::max<size_t>(tot, 1)));
+            o[nout] = HankelOut{d_out[k], shifts[k], 0, 0};
+            which[nout++] = k;
+        }
+    for (int k = nout; k < 3; ++k) o[k] = HankelOut{nullptr, 0, 0, 0};
+    if (nout > 0 && B > 0) {
+        const int tiles = (mmax + HK_TILE - 1) / HK_TILE;
+        hipLaunchKernelGGL(k_hankel, dim3(tiles, tiles, B), dim3(256), 0, ctx->stream, d_items, (const int*)nullptr,
+                           d_sig, N, nout, o[0], o[1], o[2]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < nout; ++k)
+            HIPCHK(hipMemcpy(host_out[which[k]], d_out[which[k]], sizeof(cd) * tot, hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < 3; ++k) hipFree(d_out[k]);
+    hipFree(d_sig);
+    hipFree(d_items);
+    return KBDM_OK;
+}
+
+static int stage_plan(kbdm_ctx* ctx, int B, const int32_t* n, kbdm_plan** out) {
+    kbdm_plan* pl = new kbdm_plan();
+    pl->ctx = ctx; pl->S = 0; pl->N = 0; pl->B = B; pl->p = 1;
+    int r = plan_build(pl, nullptr, n, nullptr);
+    if (!r) r = plan_alloc(pl);
+    if (r) { kbdm_plan_destroy(pl); return r; }
+    *out = pl;
+    return KBDM_OK;
+}
+
+int kbdm_svd_batch(kbdm_ctx* ctx, const double* A, int B, const int32_t* m, double* L, double* s, double* R,
+                   int32_t* status) {
+    if (!ctx || !A || !m) return fail(KBDM_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    kbdm_plan* pl = nullptr;
+    int r = stage_plan(ctx, B, m, &pl);
+    if (r) return r;
+    size_t tot = 0;
+    for (auto& it : pl->items) tot += (size_t)it.m * it.m;
+    cd* d_dense = nullptr;
+    hipStream_t st = ctx->stream;
+    r = KBDM_OK;
+    do {
+        if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
+        hipMemcpy(d_dense, A, sizeof(cd) * tot, hipMemcpyHostToDevice);
+        hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
+        for (auto& ch : pl->chunks) {
+            // stage plans are built in one chunk by construction of the tests; handle generally
+            hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_A, 0);
+            if ((r = launch_svd(pl, ch, nullptr))) break;
+        }
+        if (r) break;
+        if (hipStreamSynchronize(st) != hipSuccess) { r = fail(KBDM_E_HIP, "svd stage failed"); break; }
+        if (L) {
+            hipLaunchKernelGGL(k_transpose_out, dim3(64, B), dim3(256), 0, st, pl->d_items, pl->d_arena, KB_BUF_A, d_dense, 0);
+            hipStreamSynchronize(st);
+            hipMemcpy(L, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost);
+        }
+        if (R) {
+            hipLaunchKernelGGL(k_transpose_out, dim3(64, B), dim3(256), 0, st, pl->d_items, pl->d_arena, KB_BUF_R, d_dense, 0);
+            hipStreamSynchronize(st);
+            hipMemcpy(R, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost);
+        }
+        if (s) hipMemcpy(s, pl->d_sv, sizeof(double) * pl->total_sv, hipMemcpyDeviceToHost);
+        if (status) hipMemcpy(status, pl->d_status, sizeof(int) * B, hipMemcpyDeviceToHost);
+        if (hipGetLastError() != hipSuccess) r = fail(KBDM_E_HIP, "svd stage copy failed");
+    } while (0);
+    hipFree(d_dense);
+    if (pl->chunks.size() > 1) r = fail(KBDM_E_NOMEM, "stage API batch exceeds the workspace budget");
+    kbdm_plan_destroy(pl);
+    return r;
+}
+
+__global__ void k_fill_ones(const KbItem* items, double* varena) {
+    const KbItem it = items[blockIdx.x];
+    for (int i = threadIdx.x; i < it.l; i += blockDim.x) varena[it.voff + KB_V_DSQI * it.vstride + i] = 1.0;
+}
+
+int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, double* mu, double* P, int32_t* status) {
+    if (!ctx || !W || !n) return fail(KBDM_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    kbdm_plan* pl = nullptr;
+    int r = stage_plan(ctx, B, n, &pl);
+    if (r) return r;
+    size_t tot = 0;
+    for (auto& it : pl->items) tot += (size_t)it.m * it.m;
+    cd* d_dense = nullptr;
+    hipStream_t st = ctx->stream;
+    do {
+        if (pl->chunks.size() > 1) { r = fail(KBDM_E_NOMEM, "stage API batch exceeds the workspace budget"); break; }
+        if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
+        hipMemcpy(d_dense, W, sizeof(cd) * tot, hipMemcpyHostToDevice);
+        hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
+        Chunk& ch = pl->chunks[0];
+        hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_P, 1);
+        hipLaunchKernelGGL(k_fill_ones, dim3(B), dim3(256), 0, st, pl->d_items, pl->d_varena);
+        if ((r = launch_eig(pl, ch, nullptr))) break;
+        launch_gemm<3>(pl, ch, ch.lmax, ch.lmax);   // P = Qh X (Dsqi = 1)
+        hipLaunchKernelGGL(k_transpose_out, dim3(64, B), dim3(256), 0, st, pl->d_items, pl->d_arena, KB_BUF_P, d_dense, 1);
+        if (hipStreamSynchronize(st) != hipSuccess) { r = fail(KBDM_E_HIP, "eig stage failed"); break; }
+        if (P) hipMemcpy(P, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost);
+        if (mu) hipMemcpy(mu, pl->d_mu, sizeof(cd) * pl->total_lines, hipMemcpyDeviceToHost);
+        if (status) hipMemcpy(status, pl->d_status, sizeof(int) * B, hipMemcpyDeviceToHost);
+        if (hipGetLastError() != hipSuccess) r = fail(KBDM_E_HIP, "eig stage copy failed");
+    } while (0);
+    hipFree(d_dense);
+    kbdm_plan_destroy(pl);
+    return r;
+}
+
+}  // extern "C"

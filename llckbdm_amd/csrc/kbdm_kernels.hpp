@@ -1,0 +1,348 @@
+// gfx950 kernels of the KBDM ensemble pipeline.  One launch of each kernel covers the whole
+// batch of ensemble members ("items"); factorisation kernels give one workgroup to each
+// item (largest items first), contraction kernels tile every item over the grid.
+//
+// Pipeline (reference kbdm.py:64-92 per member; sampling.py:52-70 over members):
+//   k_hankel   U^{p-1} from the shared signal                      (kbdm.py:95-130)
+//   k_svd_fac  bidiagonalisation + explicit Q, P                    (kbdm.py:166)
+//   k_bdsqr    bidiagonal QR + sort  -> L, s, R                     (kbdm.py:166)
+//   k_gemm<1>  T1 = U^p R_        (U^p read straight from the signal: Hankel operand)
+//   k_gemm<2>  W  = Dsqi L_^H T1 Dsqi                               (kbdm.py:168-189)
+//   k_hess     Hessenberg reduction + Qh + copies                   (kbdm.py:192)
+//   k_hqr      eigenvalues (active-block single-shift QR)           (kbdm.py:192)
+//   k_invit    eigenvectors by inverse iteration                    (kbdm.py:192)
+//   k_gemm<3>  G  = Dsqi (Qh X)                                     (kbdm.py:198)
+//   k_gemm<4>  B  = R_ G                                            (kbdm.py:198)
+//   k_gemm<5>  T  = U0 B          (U0 read from the signal)         (kbdm.py:232)
+//   k_epilogue N_k, D_k, A, T2, F, PH, keep mask                    (kbdm.py:71-90, sampling.py:75-97)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kb_eig.hpp"
+#include "kb_svd.hpp"
+#include "kbdm_device.h"
+
+using namespace kb;
+
+extern __shared__ __attribute__((aligned(16))) char kb_smem[];
+
+__device__ __forceinline__ DevCtx make_ctx(int smem_bytes) {
+    DevCtx c;
+    c.smem = kb_smem;
+    c.smem_bytes = smem_bytes;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------
+// K1: Hankel assembly.  U^{s}[i,j] = c[i+j+s].  Each workgroup stages the 2*TILE-1 signal
+// samples its tile needs in LDS (one coalesced read), then streams coalesced 16-byte
+// stores.  Hankel matrices are symmetric, so row-major and column-major coincide.
+// grid = (tiles_x, tiles_y, B); outputs selected by the launch (pipeline: only U^{p-1}).
+constexpr int HK_TILE = 64;
+
+__global__ void __launch_bounds__(256) k_hankel(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                 const cd* __restrict__ signals, int N, int nout,
+                                                 HankelOut o0, HankelOut o1, HankelOut o2) {
+    const KbItem it = items[perm ? perm[blockIdx.z] : blockIdx.z];
+    const int m = it.m;
+    const int r0 = blockIdx.y * HK_TILE, c0 = blockIdx.x * HK_TILE;
+    if (r0 >= m || c0 >= m) return;
+    __shared__ cd seg[2 * HK_TILE + 8];
+    const cd* sig = signals + (size_t)it.sig * N;
+    const HankelOut outs[3] = {o0, o1, o2};
+    for (int q = 0; q < nout; ++q) {
+        const int shift = outs[q].shift;
+        cd* dst = outs[q].base + (outs[q].use_item_off ? it.off[outs[q].buf] : it.hk_off);
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * HK_TILE - 1; t += blockDim.x) {
+            const int idx = r0 + c0 + shift + t;
+            seg[t] = (idx < N) ? sig[idx] : czero();
+        }
+        __syncthreads();
+        // 64x64 tile, thread -> (column-of-memory-row i fastest): element (r, c) at dst[c*m + r]
+        for (int e = threadIdx.x; e < HK_TILE * HK_TILE; e += blockDim.x) {
+            const int i = e % HK_TILE, j = e / HK_TILE;
+            const int r = r0 + i, c = c0 + j;
+            if (r < m && c < m) dst[(size_t)c * m + r] = seg[i + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// One workgroup per item: bidiagonalisation + Q + P.
+__global__ void __launch_bounds__(1024) k_svd_fac(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                   cd* arena, double* varena, int smem_bytes) {
+    const KbItem it = items[perm[blockIdx.x]];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const int m = it.m;
+    cd* A = arena + it.off[KB_BUF_A];
+    cd* Q = arena + it.off[KB_BUF_Q];
+    cd* P = arena + it.off[KB_BUF_P];
+    double* dv = varena + it.voff;
+    double* d = dv + KB_V_D * it.vstride;
+    double* e = dv + KB_V_E * it.vstride;
+    cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);
+    cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride);
+    bidiag(ctx, m, A, m, d, e, tauq, taup);
+    gen_q(ctx, m, A, m, tauq, Q, m);
+    gen_p(ctx, m, A, m, taup, P, m);
+}
+
+__global__ void __launch_bounds__(1024) k_bdsqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                 cd* arena, double* varena, double* sv_out,
+                                                 int* status, int smem_bytes) {
+    const int item = perm[blockIdx.x];
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const int m = it.m;
+    cd* Q = arena + it.off[KB_BUF_Q];
+    cd* P = arena + it.off[KB_BUF_P];
+    cd* L = arena + it.off[KB_BUF_A];
+    cd* R = arena + it.off[KB_BUF_R];
+    double* dv = varena + it.voff;
+    double* d = dv + KB_V_D * it.vstride;
+    double* e = dv + KB_V_E * it.vstride;
+    double* s = dv + KB_V_S * it.vstride;
+    double* dsqi = dv + KB_V_DSQI * it.vstride;
+    __shared__ int info;
+    bdsqr(ctx, m, d, e, Q, m, P, m, &info);
+    sort_sv(ctx, m, d, Q, m, P, m, s, L, m, R, m);
+    // singular values out + the scaling Dsqi = 1/sqrt(s) (q = 0) or 1/sqrt(s + q^2/s)  [kbdm.py:179-186]
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const double si = s[i];
+        if (sv_out) sv_out[it.sv_off + i] = si;
+        if (i < it.l) dsqi[i] = (it.q > 0.0) ? 1.0 / sqrt(si + it.q * it.q / si) : 1.0 / sqrt(si);
+    }
+    if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_SVD_NOCONV;
+}
+
+// ------------------------------------------------------------------------------------
+// Batched complex GEMM, 32x32 tile per workgroup (v0: FP64 vector FMAs through LDS tiles).
+//   AMODE 0: A is M x K column-major          AMODE 1: A_op = A^H, A stored K x M
+//   AMODE 2: A_op[i,k] = signal[i + k + shift] (Hankel operand generated on the fly)
+struct GemmArgs {
+    int M, N, K;
+    const cd* A; int lda; int amode; int shift;
+    const cd* B; int ldb;
+    cd* C; int ldc;
+    const double* rs; const double* cs;   // optional row / column scalings of C
+};
+
+template <int STAGE>
+__device__ __forceinline__ GemmArgs gemm_setup(const KbItem& it, const cd* signals, int N, int p,
+                                               cd* arena, double* varena) {
+    GemmArgs g;
+    const int m = it.m, l = it.l;
+    const double* dsqi = varena + it.voff + KB_V_DSQI * it.vstride;
+    const cd* sig = signals + (size_t)it.sig * N;
+    g.rs = nullptr; g.cs = nullptr; g.shift = 0;
+    if (STAGE == 1) {        // T1 = U^p R_
+        g.M = m; g.N = l; g.K = m; g.A = sig; g.lda = 0; g.amode = 2; g.shift = p;
+        g.B = arena + it.off[KB_BUF_R]; g.ldb = m; g.C = arena + it.off[KB_BUF_Q]; g.ldc = m;
+    } else if (STAGE == 2) { // W = Dsqi L_^H T1 Dsqi
+        g.M = l; g.N = l; g.K = m; g.A = arena + it.off[KB_BUF_A]; g.lda = m; g.amode = 1;
+        g.B = arena + it.off[KB_BUF_Q]; g.ldb = m; g.C = arena + it.off[KB_BUF_P]; g.ldc = l;
+        g.rs = dsqi; g.cs = dsqi;
+    } else if (STAGE == 3) { // G = Dsqi (Qh X)
+        g.M = l; g.N = l; g.K = l; g.A = arena + it.off[KB_BUF_Q]; g.lda = l; g.amode = 0;
+        g.B = arena + it.off[KB_BUF_H]; g.ldb = l; g.C = arena + it.off[KB_BUF_P]; g.ldc = l;
+        g.rs = dsqi;
+    } else if (STAGE == 4) { // B = R_ G
+        g.M = m; g.N = l; g.K = l; g.A = arena + it.off[KB_BUF_R]; g.lda = m; g.amode = 0;
+        g.B = arena + it.off[KB_BUF_P]; g.ldb = l; g.C = arena + it.off[KB_BUF_A]; g.ldc = m;
+    } else {                 // T = U0 B
+        g.M = m; g.N = l; g.K = m; g.A = sig; g.lda = 0; g.amode = 2; g.shift = 0;
+        g.B = arena + it.off[KB_BUF_A]; g.ldb = m; g.C = arena + it.off[KB_BUF_Q]; g.ldc = m;
+    }
+    return g;
+}
+
+constexpr int GT = 32;   // tile edge
+constexpr int GK = 16;   // k step
+
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                               const cd* __restrict__ signals, int N, int p, cd* arena,
+                                               double* varena) {
+    const KbItem it = items[perm[blockIdx.z]];
+    const GemmArgs g = gemm_setup<STAGE>(it, signals, N, p, arena, varena);
+    const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
+    if (i0 >= g.M || j0 >= g.N) return;
+    __shared__ cd As[GK][GT + 1];
+    __shared__ cd Bs[GK][GT + 1];
+    const int t = threadIdx.x;
+    const int tx = t & 15, ty = t >> 4;
+    cd c00 = czero(), c01 = czero(), c10 = czero(), c11 = czero();
+    for (int k0 = 0; k0 < g.K; k0 += GK) {
+        // ---- stage A tile (GT rows x GK k)
+        if (g.amode == 0) {
+            for (int e = t; e < GT * GK; e += 256) {
+                const int i = e % GT, kk = e / GT;
+                const int gi = i0 + i, gk = k0 + kk;
+                As[kk][i] = (gi < g.M && gk < g.K) ? g.A[gi + (size_t)gk * g.lda] : czero();
+            }
+        } else if (g.amode == 1) {
+            for (int e = t; e < GT * GK; e += 256) {
+                const int kk = e % GK, i = e / GK;
+                const int gi = i0 + i, gk = k0 + kk;
+                As[kk][i] = (gi < g.M && gk < g.K) ? conj(g.A[gk + (size_t)gi * g.lda]) : czero();
+            }
+        } else {
+            for (int e = t; e < GT * GK; e += 256) {
+                const int i = e % GT, kk = e / GT;
+                const int gi = i0 + i, gk = k0 + kk;
+                As[kk][i] = (gi < g.M && gk < g.K) ? g.A[gi + gk + g.shift] : czero();
+            }
+        }
+        // ---- stage B tile (GK k x GT cols)
+        for (int e = t; e < GT * GK; e += 256) {
+            const int kk = e % GK, j = e / GK;
+            const int gj = j0 + j, gk = k0 + kk;
+            Bs[kk][j] = (gj < g.N && gk < g.K) ? g.B[gk + (size_t)gj * g.ldb] : czero();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            const cd a0 = As[kk][tx], a1 = As[kk][tx + 16];
+            const cd b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
+            cfma(c00, a0, b0); cfma(c01, a0, b1); cfma(c10, a1, b0); cfma(c11, a1, b1);
+        }
+        __syncthreads();
+    }
+    const int gi0 = i0 + tx, gi1 = i0 + tx + 16, gj0 = j0 + ty, gj1 = j0 + ty + 16;
+    const double r0 = (g.rs && gi0 < g.M) ? g.rs[gi0] : 1.0, r1 = (g.rs && gi1 < g.M) ? g.rs[gi1] : 1.0;
+    const double s0 = (g.cs && gj0 < g.N) ? g.cs[gj0] : 1.0, s1 = (g.cs && gj1 < g.N) ? g.cs[gj1] : 1.0;
+    if (gi0 < g.M && gj0 < g.N) g.C[gi0 + (size_t)gj0 * g.ldc] = (r0 * s0) * c00;
+    if (gi0 < g.M && gj1 < g.N) g.C[gi0 + (size_t)gj1 * g.ldc] = (r0 * s1) * c01;
+    if (gi1 < g.M && gj0 < g.N) g.C[gi1 + (size_t)gj0 * g.ldc] = (r1 * s0) * c10;
+    if (gi1 < g.M && gj1 < g.N) g.C[gi1 + (size_t)gj1 * g.ldc] = (r1 * s1) * c11;
+}
+
+
+// ------------------------------------------------------------------------------------
+// Hessenberg reduction of W (in KB_BUF_P), Qh -> KB_BUF_Q, work copy -> KB_BUF_H,
+// transposed copy -> KB_BUF_T, ||H||_inf -> varena.
+__global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                cd* arena, double* varena, int smem_bytes) {
+    const KbItem it = items[perm[blockIdx.x]];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const int n = it.l;
+    cd* W = arena + it.off[KB_BUF_P];
+    cd* Qh = arena + it.off[KB_BUF_Q];
+    cd* Hc = arena + it.off[KB_BUF_H];
+    cd* Ht = arena + it.off[KB_BUF_T];
+    double* dv = varena + it.voff;
+    cd* tauh = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);   // tauq is dead by now
+    gehd2(ctx, n, W, n, tauh);
+    gen_qh(ctx, n, W, n, tauh, Qh, n);
+    hess_copies(ctx, n, W, n, Hc, n, Ht, n);
+    double rmax = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double r = 0.0;
+        const int jlo = i > 0 ? i - 1 : 0;
+        for (int j = jlo; j < n; ++j) r += cabs(Hc[i + (size_t)j * n]);
+        rmax = fmax(rmax, r);
+    }
+    rmax = ctx.block_max(rmax);
+    if (threadIdx.x == 0) dv[KB_V_MISC * it.vstride] = rmax;
+}
+
+__global__ void __launch_bounds__(1024) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                               cd* arena, double* varena, cd* mu_out, int* status,
+                                               int smem_bytes) {
+    const int item = perm[blockIdx.x];
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    cd* Hc = arena + it.off[KB_BUF_H];
+    cd* mu = mu_out + it.line_off;
+    __shared__ int info;
+    hqr_eigvals(ctx, it.l, Hc, it.l, mu, &info);
+    if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
+}
+
+__global__ void __launch_bounds__(1024) k_invit(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                 cd* arena, double* varena, const cd* mu_out, int* status,
+                                                 int smem_bytes) {
+    const int item = perm[blockIdx.x];
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const int n = it.l;
+    const cd* Ht = arena + it.off[KB_BUF_T];
+    cd* X = arena + it.off[KB_BUF_H];
+    cd* UT = arena + it.off[KB_BUF_UT];
+    const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
+    int nw = ctx.scratch_bytes() / invit_scratch_bytes_per_wave(n);
+    if (nw > ctx.nwaves()) nw = ctx.nwaves();
+    if (nw > it.ut_waves) nw = it.ut_waves;
+    __shared__ int weak;
+    if (threadIdx.x == 0) weak = 0;
+    __syncthreads();
+    invit(ctx, n, Ht, n, mu_out + it.line_off, hnorm, UT, X, n, nw, &weak);
+    __syncthreads();
+    if (threadIdx.x == 0 && weak) status[item] |= KB_STAT_INVIT_WEAK;
+}
+
+// ------------------------------------------------------------------------------------
+// Epilogue (kbdm.py:71-90 + sampling.py:75-97).  One wavefront per spectral line k:
+//   N_k = sum_i B[i,k] T[i,k]   (bilinear, unconjugated)      D_sqrt = c[:m] . b_k / sqrt(N_k)
+//   D = D_sqrt^2 = (c.b)^2 / N,  A = |D|, PH = arg D,  F = arg(mu)/(2 pi dwell), T2 = -dwell/ln|mu|
+__global__ void __launch_bounds__(256) k_epilogue(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                   const cd* __restrict__ signals, int N, const cd* arena,
+                                                   const cd* mu_all, double dwell, double* lines,
+                                                   unsigned char* keep) {
+    const KbItem it = items[perm[blockIdx.y]];
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= it.l) return;
+    const int lane = threadIdx.x & 63;
+    const int m = it.m;
+    const cd* Bm = arena + it.off[KB_BUF_A] + (size_t)k * m;
+    const cd* T = arena + it.off[KB_BUF_Q] + (size_t)k * m;
+    const cd* sig = signals + (size_t)it.sig * N;
+    cd nk = czero(), ds = czero();
+    for (int i = lane; i < m; i += 64) {
+        const cd b = Bm[i];
+        cfma(nk, b, T[i]);
+        cfma(ds, sig[i], b);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nk.x += __shfl_xor(nk.x, o, 64); nk.y += __shfl_xor(nk.y, o, 64);
+        ds.x += __shfl_xor(ds.x, o, 64); ds.y += __shfl_xor(ds.y, o, 64);
+    }
+    if (lane == 0) {
+        const cd mu = mu_all[it.line_off + k];
+        const cd D = cdiv(ds * ds, nk);
+        const double A = hypot(D.x, D.y);
+        const double PH = atan2(D.y, D.x);
+        const double lnabs = log(hypot(mu.x, mu.y));
+        const double T2 = -dwell / lnabs;
+        const double F = atan2(mu.y, mu.x) / (6.283185307179586476925286766559 * dwell);
+        double* out = lines + 4 * (it.line_off + k);
+        out[0] = A; out[1] = T2; out[2] = F; out[3] = PH;
+        keep[it.line_off + k] = (A > 1e-6 && T2 > 0.0) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Layout helpers for the stage entry points (row-major host matrices <-> column-major).
+__global__ void k_transpose_in(const KbItem* __restrict__ items, const cd* __restrict__ src, cd* arena, int buf,
+                               int use_l) {
+    const KbItem it = items[blockIdx.y];
+    const int n = use_l ? it.l : it.m;
+    const cd* s = src + it.hk_off;
+    cd* d = arena + it.off[buf];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+        const int i = e % n, j = e / n;
+        d[i + (size_t)j * n] = s[(size_t)i * n + j];
+    }
+}
+__global__ void k_transpose_out(const KbItem* __restrict__ items, const cd* arena, int buf, cd* dst, int use_l) {
+    const KbItem it = items[blockIdx.y];
+    const int n = use_l ? it.l : it.m;
+    const cd* s = arena + it.off[buf];
+    cd* d = dst + it.hk_off;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+        const int j = e % n, i = e / n;
+        d[(size_t)i * n + j] = s[i + (size_t)j * n];
+    }
+}

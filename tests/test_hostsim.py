@@ -1,0 +1,86 @@
+"""CPU: the algorithm templates the HIP kernels instantiate (llckbdm_amd/csrc/kb_*.hpp), run
+through the one-thread host context of tests/hostsim, reproduce the reference's golden vectors.
+This checks index/convergence logic without a GPU; the GPU parity tests check the real kernels."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.helpers import canonical, assert_lines_close, genuine_rows, keep_mask
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = ctypes.c_void_p
+
+
+@pytest.fixture(scope="module")
+def hs():
+    src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
+    out_dir = os.path.join(ROOT, "tests", "hostsim", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libhostsim.so")
+    inc = os.path.join(ROOT, "llckbdm_amd", "csrc")
+    deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc)]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, src, "-o", so], check=True)
+    return ctypes.CDLL(so)
+
+
+def _kbdm(hs, sig, m, l, p, q, dwell=5e-4):
+    sig = np.ascontiguousarray(sig, dtype=complex)
+    lines, sv, mu = np.zeros((l, 4)), np.zeros(m), np.zeros(l, complex)
+    info = hs.hs_kbdm(sig.ctypes.data_as(P), len(sig), m, l, p, ctypes.c_double(q), ctypes.c_double(dwell),
+                      lines.ctypes.data_as(P), sv.ctypes.data_as(P), mu.ctypes.data_as(P))
+    return lines, sv, mu, info
+
+
+def test_svd_random_and_degenerate(hs):
+    rng = np.random.default_rng(1)
+    mats = [rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)) for m in (1, 2, 7, 33)]
+    mats.append(np.zeros((5, 5), complex))
+    mats.append(np.eye(6, dtype=complex))
+    mats.append(np.diag([3.0, -2.0, 0.0, 1e-20]).astype(complex))
+    for A in mats:
+        m = A.shape[0]
+        Af = np.asfortranarray(A)
+        L, R, s = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F"), np.zeros(m)
+        info = hs.hs_svd(Af.ctypes.data_as(P), m, L.ctypes.data_as(P), s.ctypes.data_as(P), R.ctypes.data_as(P))
+        assert info == 0
+        scale = max(1.0, np.abs(A).max())
+        assert np.abs(L @ np.diag(s) @ R.conj().T - A).max() < 1e-13 * scale * m
+        assert np.abs(L.conj().T @ L - np.eye(m)).max() < 1e-13 * m
+        assert np.abs(R.conj().T @ R - np.eye(m)).max() < 1e-13 * m
+        assert np.all(np.diff(s) <= 0) and np.all(s >= 0)
+        assert np.abs(s - np.linalg.svd(A, compute_uv=False)).max() < 1e-13 * scale * m
+
+
+def test_eig_random(hs):
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 3, 16, 40):
+        W = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        Wf = np.asfortranarray(W)
+        mu, Pm = np.zeros(n, complex), np.zeros((n, n), complex, order="F")
+        info = hs.hs_eig(Wf.ctypes.data_as(P), n, mu.ctypes.data_as(P), Pm.ctypes.data_as(P))
+        assert info == 0
+        assert np.abs(W @ Pm - Pm * mu[None, :]).max() < 1e-12 * n
+        ref = np.linalg.eigvals(W)
+        assert np.abs(mu[:, None] - ref[None, :]).min(axis=1).max() < 1e-11
+
+
+@pytest.mark.parametrize("name", ["m100", "m64p2", "m180l30", "m10q", "n3m128"])
+def test_pipeline_matches_reference_golden(hs, golden, name):
+    m, l, p = (int(x) for x in golden[f"{name}__meta"])
+    q = float(golden[f"{name}__q"][0])
+    sig = golden[str(golden[f"{name}__sig"])]
+    ll, sv, mu, info = _kbdm(hs, sig, m, l, p, q)
+    assert info == 0
+    ref_sv = golden[f"{name}__sv"]
+    assert np.abs(sv - ref_sv).max() < 1e-13 * ref_sv[0] * m
+    kept = canonical(ll[keep_mask(ll)])
+    want = golden[f"{name}__kept"]
+    assert len(kept) == len(want)
+    assert_lines_close(kept, want, rel=1e-7, phase_abs=1e-7, what=name)
+    if name == "m100":
+        truth = golden["params_sorted"]
+        assert_lines_close(genuine_rows(kept, truth), genuine_rows(want, truth), rel=1e-8, phase_abs=1e-8)
