@@ -68,19 +68,13 @@ KB_HD void gen_qh(const C& ctx, int n, const cd* W, int ld, const cd* tauh, cd* 
     }
 }
 
-// Extract the upper Hessenberg part into a work copy Hc (for the QR iteration) and its
-// transpose Ht (Ht[j + i*ld] = H[i,j]; rows of H contiguous, for the inverse iteration).
+// Extract the upper Hessenberg part of W into the work copy Hc that the QR iteration destroys
+// (W itself keeps H above its Householder vectors and later feeds the inverse iteration).
 template <class C>
-KB_HD void hess_copies(const C& ctx, int n, const cd* W, int ld, cd* Hc, int ldc, cd* Ht, int ldt) {
+KB_HD void hess_copy(const C& ctx, int n, const cd* W, int ld, cd* Hc, int ldc) {
     for (int idx = ctx.tid(); idx < n * n; idx += ctx.nthreads()) {
         const int i = idx % n, j = idx / n;
-        const cd v = (i <= j + 1) ? W[i + (size_t)j * ld] : czero();
-        Hc[i + (size_t)j * ldc] = v;
-    }
-    for (int idx = ctx.tid(); idx < n * n; idx += ctx.nthreads()) {
-        const int j = idx % n, i = idx / n;   // consecutive threads -> consecutive j (coalesced store)
-        const cd v = (i <= j + 1) ? W[i + (size_t)j * ld] : czero();
-        Ht[j + (size_t)i * ldt] = v;
+        Hc[i + (size_t)j * ldc] = (i <= j + 1) ? W[i + (size_t)j * ld] : czero();
     }
     ctx.sync();
 }
@@ -302,30 +296,41 @@ KB_HD void hqr_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info) {
 }
 
 // ---------------------------------------------------------------------------------
-// Inverse iteration for the right eigenvectors of the upper Hessenberg H (given through
-// its transpose Ht: row i of H is contiguous at Ht + i*ldt).  One wavefront per
-// eigenvalue.  LAPACK zhsein/zlaein semantics: eigenvalues closer than eps3 to an
-// earlier one are perturbed; pivots that vanish are replaced by eps3; the start vector
-// is eps3*ones; a single back-substitution normally reaches the growth criterion.
-//   UT   : per-wavefront workspace, n*n entries each (row i of the U factor contiguous)
+// Inverse iteration for the right eigenvectors of the upper Hessenberg H (LAPACK
+// zhsein/zlaein semantics: perturb eigenvalues that coincide, replace vanishing pivots by
+// eps3, start from eps3*ones, normally ONE solve reaches the growth criterion).
+//
+// GPU formulation - no O(n^2) factor is ever stored.  zlaein eliminates the subdiagonal of
+// B = H - w I by ROW operations top-down and back-substitutes bottom-up, which forces it to
+// keep U.  Here the subdiagonal is eliminated by COLUMN operations bottom-up
+//      B E_{n-2} ... E_0 = R (upper triangular),  E_j mixes columns (j, j+1) with adjacent
+//      column pivoting,
+// so R's columns become final in the order n-1, n-2, ... - exactly the order in which the
+// column-oriented back-substitution R y = b consumes them.  Elimination and substitution are
+// fused into one sweep that keeps two columns and b (O(n) state, in LDS); x = E_{n-2}..E_0 y
+// is a chain of n-1 2x2 updates.  Columns of H are contiguous (coalesced) and are fetched
+// one step ahead of the dependent chain.  One wavefront per eigenvalue.
+//   H    : n x n column-major; only rows 0..j+1 of column j are read (whatever lies below
+//          the subdiagonal - e.g. Householder vectors - is ignored)
 //   X    : n x n output, column k = eigenvector of w[k] in the Hessenberg basis
-// flags[k] = 1 if the growth criterion was not met after the retries.
-KB_HD int invit_scratch_bytes_per_wave(int n) { return 2 * n * (int)sizeof(cd); }
+KB_HD int invit_scratch_bytes_per_wave(int n) { return (3 * n + 2) * (int)sizeof(cd) + ((n + 15) & ~15); }
 
-template <class C>
-KB_HD void invit(const C& ctx, int n, const cd* Ht, int ldt, const cd* w, double hnorm, cd* UTall,
-                 cd* X, int ldx, int nwaves_used, int* weak) {
+template <class C, int MAXC>
+KB_HD void invit(const C& ctx, int n, const cd* H, int ldh, const cd* w, double hnorm, cd* X, int ldx,
+                 int nwaves_used, int* weak) {
     const int lane = ctx.lane();
     const double eps3 = fmax(hnorm * KB_ULP, KB_SAFMIN * ((double)n / KB_ULP));
     const double rootn = sqrt((double)n);
     const double growto = 0.1 / rootn;
     if (ctx.wave() >= nwaves_used) return;
-    cd* rowc = reinterpret_cast<cd*>(ctx.scratch()) + (size_t)ctx.wave() * 2 * n;
-    cd* x = rowc + n;
-    cd* UT = UTall + (size_t)ctx.wave() * n * n;
+    cd* cand = reinterpret_cast<cd*>(ctx.scratch()) + (size_t)ctx.wave() * (3 * n + 2);
+    cd* bv = cand + n + 1;        // right-hand side, becomes y, then x
+    cd* fm = bv + n + 1;          // multipliers f_j; swap flag carried in swp[]
+    unsigned char* swp = reinterpret_cast<unsigned char*>(ctx.scratch()) +
+                         (size_t)nwaves_used * (3 * n + 2) * sizeof(cd) + (size_t)ctx.wave() * n;
+    const bool fast = (n <= MAXC * C::WS);
     int nweak = 0;
     for (int kk = ctx.wave(); kk < n; kk += nwaves_used) {
-        // perturb wk away from earlier (index < kk) eigenvalues closer than eps3
         cd wk = w[kk];
         {
             int cnt = 0;
@@ -333,49 +338,9 @@ KB_HD void invit(const C& ctx, int n, const cd* Ht, int ldt, const cd* w, double
             cnt = (int)ctx.wave_sum((double)cnt);
             wk.x += cnt * eps3;
         }
-        // ---- LU of B = H - wk I with adjacent-row pivoting; row i of U -> UT[i*n + j]
-        for (int j = lane; j < n; j += C::WS) {
-            cd v = Ht[j];
-            if (j == 0) v = v - wk;
-            rowc[j] = v;
-        }
-        ctx.wave_fence();
-        for (int i = 0; i < n - 1; ++i) {
-            const cd ei = Ht[i + (size_t)(i + 1) * ldt];   // H(i+1, i)
-            cd bii = rowc[i];
-            const cd* hrow = Ht + (size_t)(i + 1) * ldt;
-            if (cabs1(bii) < cabs1(ei)) {
-                const cd xm = cdiv(bii, ei);
-                for (int j = i + 1 + lane; j < n; j += C::WS) {
-                    cd temp = hrow[j];
-                    if (j == i + 1) temp = temp - wk;
-                    UT[(size_t)i * n + j] = temp;
-                    rowc[j] = rowc[j] - xm * temp;
-                }
-                if (lane == 0) UT[(size_t)i * n + i] = ei;
-            } else {
-                if (is_zero(bii)) bii = mk(eps3, 0.0);
-                const cd xm = cdiv(ei, bii);
-                for (int j = i + 1 + lane; j < n; j += C::WS) {
-                    cd temp = hrow[j];
-                    if (j == i + 1) temp = temp - wk;
-                    const cd cur = rowc[j];
-                    UT[(size_t)i * n + j] = cur;
-                    rowc[j] = temp - xm * cur;
-                }
-                if (lane == 0) UT[(size_t)i * n + i] = bii;
-            }
-            ctx.wave_fence();
-        }
-        {
-            cd bnn = rowc[n - 1];
-            if (is_zero(bnn)) bnn = mk(eps3, 0.0);
-            if (lane == 0) UT[(size_t)(n - 1) * n + (n - 1)] = bnn;
-        }
-        ctx.wave_fence();
-        // ---- solve U x = v (v = eps3 * start vector); retry with other start vectors
         bool ok = false;
         for (int its = 0; its < 4 && !ok; ++its) {
+            // right-hand side (zlaein start vectors)
             for (int j = lane; j < n; j += C::WS) {
                 double vj;
                 if (its == 0) vj = eps3;
@@ -384,40 +349,122 @@ KB_HD void invit(const C& ctx, int n, const cd* Ht, int ldt, const cd* w, double
                     vj = (j == 0) ? eps3 : rtemp;
                     if (j == n - its) vj -= eps3 * rootn;
                 }
-                x[j] = mk(vj, 0.0);
+                bv[j] = mk(vj, 0.0);
+            }
+            // candidate for position n-1: raw column n-1 of B (rows 0..n-1)
+            for (int r = lane; r < n; r += C::WS) {
+                cd v = H[r + (size_t)(n - 1) * ldh];
+                if (r == n - 1) v = v - wk;
+                cand[r] = v;
             }
             ctx.wave_fence();
             bool rescaled = false;
-            for (int i = n - 1; i >= 0; --i) {
-                const cd* urow = UT + (size_t)i * n;
-                cd s = czero();
-                for (int j = i + 1 + lane; j < n; j += C::WS) cfma(s, urow[j], x[j]);
-                s = ctx.wave_sum(s);
-                cd xi = cdiv(x[i] - s, urow[i]);
-                const double mag = cabs1(xi);
-                if (mag > 1e120) {
-                    // rescale the whole system (solution so far and untouched right-hand side)
-                    const double sc = 1e-120;
-                    for (int j = lane; j < n; j += C::WS) x[j] = x[j] * sc;
-                    xi = xi * sc;
-                    rescaled = true;
-                    ctx.wave_fence();
+            // prefetch registers for the raw column of the next step (rows lane + WS*c)
+            cd nxt[MAXC];
+            if (fast && n >= 2) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int r = lane + c * C::WS;
+                    nxt[c] = (r <= n - 1) ? H[r + (size_t)(n - 2) * ldh] : czero();
                 }
-                if (lane == 0) x[i] = xi;
+            }
+            for (int j = n - 2; j >= 0; --j) {
+                // raw column j of B, rows 0..j+1
+                cd cur[MAXC];
+                if (fast) {
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) cur[c] = nxt[c];
+                    if (j >= 1) {
+#pragma unroll
+                        for (int c = 0; c < MAXC; ++c) {
+                            const int r = lane + c * C::WS;
+                            nxt[c] = (r <= j) ? H[r + (size_t)(j - 1) * ldh] : czero();
+                        }
+                    }
+                }
+                const cd rsub = H[(j + 1) + (size_t)j * ldh];      // B(j+1, j) = H(j+1, j)
+                cd cpiv = cand[j + 1];                              // diagonal of the candidate
+                cd f, piv;
+                const bool swap = cabs1(cpiv) < cabs1(rsub);
+                if (!swap) {
+                    if (is_zero(cpiv)) cpiv = mk(eps3, 0.0);
+                    piv = cpiv;
+                    f = cdiv(rsub, cpiv);
+                } else {
+                    piv = rsub;
+                    f = cdiv(cpiv, rsub);
+                }
+                // y_{j+1} and the right-hand side update use the FINAL column at position j+1
+                const cd yj1 = cdiv(bv[j + 1], piv);
+                ctx.wave_fence();
+                if (fast) {
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int r = lane + c * C::WS;
+                        if (r <= j) {
+                            cd raw = cur[c];
+                            if (r == j) raw = raw - wk;
+                            const cd cn = cand[r];
+                            const cd fin = swap ? raw : cn;
+                            const cd oth = swap ? cn : raw;
+                            cand[r] = oth - f * fin;          // new candidate for position j
+                            bv[r] = bv[r] - yj1 * fin;
+                        }
+                    }
+                } else {
+                    for (int r = lane; r <= j; r += C::WS) {
+                        cd raw = H[r + (size_t)j * ldh];
+                        if (r == j) raw = raw - wk;
+                        const cd cn = cand[r];
+                        const cd fin = swap ? raw : cn;
+                        const cd oth = swap ? cn : raw;
+                        cand[r] = oth - f * fin;
+                        bv[r] = bv[r] - yj1 * fin;
+                    }
+                }
+                if (lane == 0) {
+                    bv[j + 1] = yj1;
+                    fm[j] = f;
+                    swp[j] = swap ? 1 : 0;
+                }
+                // guard against overflow: rescale the whole system
+                if (cabs1(yj1) > 1e120) {
+                    ctx.wave_fence();
+                    for (int r = lane; r < n; r += C::WS) bv[r] = bv[r] * 1e-120;
+                    rescaled = true;
+                }
+                ctx.wave_fence();
+            }
+            {
+                cd p0 = cand[0];
+                if (is_zero(p0)) p0 = mk(eps3, 0.0);
+                const cd y0 = cdiv(bv[0], p0);
+                ctx.wave_fence();
+                if (lane == 0) {
+                    // x = E_{n-2} ... E_0 y : E_j acts on coordinates (j, j+1); only one value
+                    // is carried, the loads of y_{j+1}, f_j do not depend on it
+                    cd carry = y0;
+                    for (int j = 0; j <= n - 2; ++j) {
+                        const cd b = bv[j + 1], f = fm[j];
+                        const cd t = b - f * carry;
+                        if (!swp[j]) { bv[j] = carry; carry = t; }
+                        else { bv[j] = t; }
+                    }
+                    bv[n - 1] = carry;
+                }
                 ctx.wave_fence();
             }
             double vn = 0.0;
-            for (int j = lane; j < n; j += C::WS) vn += cabs1(x[j]);
+            for (int j = lane; j < n; j += C::WS) vn += cabs1(bv[j]);
             vn = ctx.wave_sum(vn);
             ok = rescaled || (vn >= growto);
         }
         if (!ok) nweak++;
-        // ---- normalise to unit max-|.|_1 entry and store
         double mx = 0.0;
-        for (int j = lane; j < n; j += C::WS) mx = fmax(mx, cabs1(x[j]));
+        for (int j = lane; j < n; j += C::WS) mx = fmax(mx, cabs1(bv[j]));
         mx = ctx.wave_max(mx);
         const double inv = (mx > 0.0) ? 1.0 / mx : 1.0;
-        for (int j = lane; j < n; j += C::WS) X[j + (size_t)kk * ldx] = x[j] * inv;
+        for (int j = lane; j < n; j += C::WS) X[j + (size_t)kk * ldx] = bv[j] * inv;
         ctx.wave_fence();
     }
     if (lane == 0 && nweak > 0) *weak = 1;   // benign race: every writer stores 1

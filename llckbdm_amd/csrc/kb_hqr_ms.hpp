@@ -1,0 +1,382 @@
+// Multi-bulge (small-bulge multishift) complex QR iteration on an upper Hessenberg matrix,
+// eigenvalues only, active block only (part of the zgeev replacement, reference kbdm.py:192).
+//
+// Why: the single-shift sweep of hqr_eigvals is a chain of ~1.5 n^2 dependent steps, each
+// costing two workgroup barriers and two global-memory round trips -> latency bound
+// (k_hqr was 45 % of the pipeline in the first profile).  Here ns shifts (eigenvalues of the
+// trailing ns x ns block, computed by ONE wavefront in LDS) drive ns 2x2 bulges that are
+// chased simultaneously, three rows apart (Braman/Byers/Mathias small-bulge chains; the
+// spacing makes the reflectors commute, so the result equals ns consecutive single-shift
+// sweeps with the same shifts).  One barrier interval now advances ns bulges: the dependent
+// chain shrinks by ~ns, the work per barrier grows by ns.
+// Small active blocks (< KB_MS_MIN) fall back to the single-shift sweep; 2x2 blocks are
+// solved in closed form.
+#pragma once
+#include "kb_eig.hpp"
+
+namespace kb {
+
+constexpr int KB_MS_MIN = 12;     // below this active size: single-shift sweeps
+constexpr int KB_MS_NSMAX = 32;   // compile-time cap on simultaneous shifts
+
+// The lanes of ONE wavefront presented as a tiny workgroup (for the small shift solver).
+template <class C>
+struct WaveCtx {
+    static constexpr int WS = C::WS;
+    const C& c;
+    char* scr;
+    int scr_bytes;
+    KB_HD int tid() const { return c.lane(); }
+    KB_HD int nthreads() const { return C::WS; }
+    KB_HD int lane() const { return c.lane(); }
+    KB_HD int wave() const { return 0; }
+    KB_HD int nwaves() const { return 1; }
+    KB_HD void sync() const { c.wave_fence(); }
+    KB_HD void wave_fence() const { c.wave_fence(); }
+    KB_HD char* scratch() const { return scr; }
+    KB_HD int scratch_bytes() const { return scr_bytes; }
+    KB_HD double wave_sum(double v) const { return c.wave_sum(v); }
+    KB_HD cd wave_sum(cd v) const { return c.wave_sum(v); }
+    KB_HD double wave_max(double v) const { return c.wave_max(v); }
+    KB_HD int wave_max(int v) const { return c.wave_max(v); }
+    KB_HD double block_sum(double v) const { c.wave_fence(); return c.wave_sum(v); }
+    KB_HD cd block_sum(cd v) const { c.wave_fence(); return c.wave_sum(v); }
+    KB_HD double block_max(double v) const { c.wave_fence(); return c.wave_max(v); }
+    KB_HD int block_max(int v) const { c.wave_fence(); return c.wave_max(v); }
+};
+
+struct MsRefl {
+    cd t1;
+    cd v2;
+    cd t2;        // t1 * v2.  zlahqr keeps only its real part, which is valid while every
+                  // subdiagonal is real; inside a multi-bulge batch H(i,i-1) is complex after
+                  // the first bulge has left the bottom, so the general complex form is used.
+    int k;        // row/column index of the bulge
+    int pad;
+};
+
+struct MsStats {          // optional instrumentation (host simulation only)
+    long long intervals, batches, single_sweeps, small_steps;
+};
+
+KB_HD int hqr_ms_scratch_bytes(int nsmax) {
+    return (nsmax * nsmax + nsmax) * (int)sizeof(cd) + nsmax * (int)sizeof(MsRefl) + 64;
+}
+
+// Eigenvalues of the 2x2 block [[a,b],[c,d]].
+KB_HD void eig2x2(cd a, cd b, cd c, cd d, cd& z1, cd& z2) {
+    const cd s = 0.5 * (a + d);
+    const cd p = 0.5 * (a - d);
+    const cd disc = csqrt_(p * p + b * c);
+    const cd e1 = s + disc, e2 = s - disc;
+    const cd det = a * d - b * c;
+    if (cabs1(e1) >= cabs1(e2)) {
+        z1 = e1;
+        z2 = is_zero(e1) ? e2 : cdiv(det, e1);
+    } else {
+        z1 = e2;
+        z2 = cdiv(det, e2);
+    }
+}
+
+// One single-shift QR sweep on the active block [l..i] (zlahqr body).  Same code path as
+// hqr_eigvals; kept separate so that the multishift driver can use it for small blocks.
+template <class C>
+KB_HD void single_shift_sweep(const C& ctx, cd* H, int ld, int l, int i, int kdefl) {
+#define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
+    const double ulp = KB_ULP;
+    const int tid = ctx.tid(), nt = ctx.nthreads();
+    cd t;
+    if (kdefl % 20 == 0) {
+        t = mk(0.75 * fabs(HH(i, i - 1).x), 0.0) + HH(i, i);
+    } else if (kdefl % 10 == 0) {
+        t = mk(0.75 * fabs(HH(l + 1, l).x), 0.0) + HH(l, l);
+    } else {
+        t = HH(i, i);
+        const cd u = csqrt_(HH(i - 1, i)) * csqrt_(HH(i, i - 1));
+        double s = cabs1(u);
+        if (s != 0.0) {
+            const cd x = 0.5 * (HH(i - 1, i - 1) - t);
+            const double sx = cabs1(x);
+            s = fmax(s, sx);
+            const cd xs = mk(x.x / s, x.y / s), us = mk(u.x / s, u.y / s);
+            cd y = s * csqrt_(xs * xs + us * us);
+            if (sx > 0.0) {
+                const cd xn = mk(x.x / sx, x.y / sx);
+                if (xn.x * y.x + xn.y * y.y < 0.0) y = -y;
+            }
+            t = t - u * cdiv(u, x + y);
+        }
+    }
+    int mf = l;
+    for (int mm = l + 1 + tid; mm <= i - 1; mm += nt) {
+        const cd h11 = HH(mm, mm), h22 = HH(mm + 1, mm + 1);
+        cd h11s = h11 - t;
+        double h21 = HH(mm + 1, mm).x;
+        const double s = cabs1(h11s) + fabs(h21);
+        h11s = mk(h11s.x / s, h11s.y / s);
+        h21 = h21 / s;
+        const double h10 = HH(mm, mm - 1).x;
+        if (fabs(h10) * fabs(h21) <= ulp * (cabs1(h11s) * (cabs1(h11) + cabs1(h22))))
+            if (mm > mf) mf = mm;
+    }
+    mf = ctx.block_max(mf);
+    const int ms = mf;
+    cd v1, v2;
+    {
+        cd h11s = HH(ms, ms) - t;
+        double h21 = HH(ms + 1, ms).x;
+        const double s = cabs1(h11s) + fabs(h21);
+        v1 = mk(h11s.x / s, h11s.y / s);
+        v2 = mk(h21 / s, 0.0);
+    }
+    for (int k = ms; k <= i - 1; ++k) {
+        if (k > ms) { v1 = HH(k, k - 1); v2 = HH(k + 1, k - 1); }
+        cd t1;
+        larfg2(v1, v2, t1);
+        ctx.sync();
+        if (k > ms && tid == 0) { HH(k, k - 1) = v1; HH(k + 1, k - 1) = czero(); }
+        const double t2 = (t1 * v2).x;
+        for (int j = k + tid; j <= i; j += nt) {
+            const cd a = HH(k, j), b = HH(k + 1, j);
+            const cd sum = conj(t1) * a + t2 * b;
+            HH(k, j) = a - sum;
+            HH(k + 1, j) = b - sum * v2;
+        }
+        ctx.sync();
+        const int rmax = (k + 2 < i) ? k + 2 : i;
+        for (int j = l + tid; j <= rmax; j += nt) {
+            const cd a = HH(j, k), b = HH(j, k + 1);
+            const cd sum = t1 * a + t2 * b;
+            HH(j, k) = a - sum;
+            HH(j, k + 1) = b - sum * conj(v2);
+        }
+        ctx.sync();
+        if (k == ms && ms > l) {
+            cd temp = mk(1.0, 0.0) - t1;
+            const double at = cabs(temp);
+            temp = mk(temp.x / at, temp.y / at);
+            if (tid == 0) {
+                HH(ms + 1, ms) = HH(ms + 1, ms) * conj(temp);
+                if (ms + 2 <= i) HH(ms + 2, ms + 1) = HH(ms + 2, ms + 1) * temp;
+            }
+            ctx.sync();
+            const int len = i - l + 1;
+            for (int idx = tid; idx < len * len; idx += nt) {
+                const int r = l + idx % len, c = l + idx / len;
+                if (r < c) {
+                    const bool rin = (r >= ms && r != ms + 1);
+                    const bool cin = (c >= ms && c != ms + 1);
+                    if (rin || cin) {
+                        cd v = HH(r, c);
+                        if (rin) v = v * temp;
+                        if (cin) v = v * conj(temp);
+                        HH(r, c) = v;
+                    }
+                }
+            }
+            ctx.sync();
+        }
+    }
+#undef HH
+}
+
+template <class C>
+KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, int nsmax,
+                          MsStats* stats = nullptr) {
+#define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
+    const double ulp = KB_ULP;
+    const double smlnum = KB_SAFMIN * ((double)n / ulp);
+    const int tid = ctx.tid(), nt = ctx.nthreads();
+    if (nsmax > KB_MS_NSMAX) nsmax = KB_MS_NSMAX;
+    cd* S = reinterpret_cast<cd*>(ctx.scratch());
+    cd* sh = S + nsmax * nsmax;
+    MsRefl* refl = reinterpret_cast<MsRefl*>(sh + nsmax);
+    int* sinfo = reinterpret_cast<int*>(refl + nsmax);
+    int fail = 0;
+    if (n == 1) {
+        if (tid == 0) { w[0] = HH(0, 0); *info = 0; }
+        ctx.sync();
+        return;
+    }
+    // make every subdiagonal real (diagonal unitary similarity; eigenvalues unchanged)
+    for (int i = 1; i < n; ++i) {
+        ctx.sync();
+        const cd hs = HH(i, i - 1);
+        if (hs.y != 0.0) {
+            const double a = cabs(hs);
+            const cd sc = mk(hs.x / a, -hs.y / a);
+            ctx.sync();
+            if (tid == 0) {
+                HH(i, i - 1) = mk(a, 0.0);
+                if (i + 1 < n) HH(i + 1, i) = HH(i + 1, i) * conj(sc);
+            }
+            for (int j = i + 1 + tid; j < n; j += nt) HH(i, j) = HH(i, j) * sc;
+            for (int r = tid; r < i; r += nt) HH(r, i) = HH(r, i) * conj(sc);
+        }
+    }
+    ctx.sync();
+    const int itmax = 30 * (n > 10 ? n : 10);
+    int kdefl = 0;
+    int i = n - 1;
+    while (i >= 0) {
+        int l = 0;
+        int done = 0;   // 1: H(i,i) converged, 2: 2x2 block solved
+        for (int its = 0; its <= itmax; ++its) {
+            // ---- deflation scan: largest k in (l, i] with a negligible subdiagonal
+            int kf = l;
+            for (int k = l + 1 + tid; k <= i; k += nt) {
+                const cd hkk1 = HH(k, k - 1);
+                bool small_ = false;
+                if (cabs1(hkk1) <= smlnum) small_ = true;
+                else {
+                    double tst = cabs1(HH(k - 1, k - 1)) + cabs1(HH(k, k));
+                    if (tst == 0.0) {
+                        if (k - 2 >= 0) tst += fabs(HH(k - 1, k - 2).x);
+                        if (k + 1 <= n - 1) tst += fabs(HH(k + 1, k).x);
+                    }
+                    if (fabs(hkk1.x) <= ulp * tst) {
+                        const double a1 = cabs1(hkk1), a2 = cabs1(HH(k - 1, k));
+                        const double ab = fmax(a1, a2), ba = fmin(a1, a2);
+                        const cd df = HH(k - 1, k - 1) - HH(k, k);
+                        const double b1 = cabs1(HH(k, k)), b2 = cabs1(df);
+                        const double aa = fmax(b1, b2), bb = fmin(b1, b2);
+                        const double s = aa + ab;
+                        if (ba * (ab / s) <= fmax(smlnum, ulp * (bb * (aa / s)))) small_ = true;
+                    }
+                }
+                if (small_ && k > kf) kf = k;
+            }
+            kf = ctx.block_max(kf);
+            l = kf;
+            if (l > 0 && tid == 0) HH(l, l - 1) = czero();
+            if (l >= i) { done = 1; break; }
+            ctx.sync();
+            const int na = i - l + 1;
+            if (na == 2) {
+                if (tid == 0) {
+                    cd z1, z2;
+                    eig2x2(HH(l, l), HH(l, i), HH(i, l), HH(i, i), z1, z2);
+                    w[l] = z1; w[i] = z2;
+                }
+                done = 2;
+                break;
+            }
+            kdefl++;
+            if (na < KB_MS_MIN || nsmax < 2) {
+                single_shift_sweep(ctx, H, ld, l, i, kdefl);
+                if (stats && tid == 0) stats->single_sweeps++;
+            } else {
+                int ns = na / 3;
+                if (ns > nsmax) ns = nsmax;
+                if (ns < 2) ns = 2;
+                // ---- shifts
+                if (kdefl % 6 == 0) {
+                    // exceptional shifts (zlaqr0): h(ii,ii) + 0.75 |h(ii,ii-1)|, in pairs
+                    for (int b = tid; b < ns; b += nt) {
+                        const int ii = i - (b & ~1);
+                        sh[b] = HH(ii, ii) + mk(0.75 * cabs1(HH(ii, ii - 1)), 0.0);
+                    }
+                } else {
+                    const int r0 = i - ns + 1;
+                    for (int idx = tid; idx < ns * ns; idx += nt) {
+                        const int r = idx % ns, c = idx / ns;
+                        S[r + c * ns] = (r <= c + 1) ? HH(r0 + r, r0 + c) : czero();
+                    }
+                    ctx.sync();
+                    if (ctx.wave() == 0) {
+                        WaveCtx<C> wc{ctx, nullptr, 0};
+                        hqr_eigvals(wc, ns, S, ns, sh, sinfo);
+                    }
+                }
+                ctx.sync();
+                // ---- pipelined chase of ns bulges, 3 rows apart
+                const int T = (na - 1) + 3 * (ns - 1);
+                for (int t = 0; t < T; ++t) {
+                    // active bulges: 0 <= t - 3b <= na - 2
+                    int b_hi = t / 3;
+                    if (b_hi > ns - 1) b_hi = ns - 1;
+                    int b_lo = (t - (na - 2) + 2) / 3;
+                    if (t - (na - 2) <= 0) b_lo = 0;
+                    // phase 0: reflectors (one thread per bulge)
+                    for (int b = b_lo + tid; b <= b_hi; b += nt) {
+                        const int k = l + t - 3 * b;
+                        cd v1, v2, t1;
+                        if (k == l) {
+                            cd h11s = HH(l, l) - sh[b];
+                            const cd h21 = HH(l + 1, l);
+                            const double s = cabs1(h11s) + cabs1(h21);
+                            if (s == 0.0) { v1 = czero(); v2 = czero(); }
+                            else { v1 = mk(h11s.x / s, h11s.y / s); v2 = mk(h21.x / s, h21.y / s); }
+                        } else {
+                            v1 = HH(k, k - 1);
+                            v2 = HH(k + 1, k - 1);
+                        }
+                        larfg2(v1, v2, t1);
+                        if (k > l) { HH(k, k - 1) = v1; HH(k + 1, k - 1) = czero(); }
+                        refl[b].t1 = t1; refl[b].v2 = v2; refl[b].t2 = t1 * v2; refl[b].k = k;
+                    }
+                    ctx.sync();
+                    // phase R: rows k, k+1 ; columns k..i
+                    for (int b = b_lo; b <= b_hi; ++b) {
+                        const MsRefl rf = refl[b];
+                        const int k = rf.k;
+                        const cd ct1 = conj(rf.t1), ct2 = conj(rf.t2);
+                        for (int j = k + tid; j <= i; j += nt) {
+                            const cd a = HH(k, j), bb = HH(k + 1, j);
+                            const cd sum = ct1 * a + ct2 * bb;
+                            HH(k, j) = a - sum;
+                            HH(k + 1, j) = bb - sum * rf.v2;
+                        }
+                    }
+                    ctx.sync();
+                    // phase C: columns k, k+1 ; rows l..min(k+2, i)
+                    for (int b = b_lo; b <= b_hi; ++b) {
+                        const MsRefl rf = refl[b];
+                        const int k = rf.k;
+                        const int rmax = (k + 2 < i) ? k + 2 : i;
+                        const cd cv2 = conj(rf.v2);
+                        for (int j = l + tid; j <= rmax; j += nt) {
+                            const cd a = HH(j, k), bb = HH(j, k + 1);
+                            const cd sum = rf.t1 * a + rf.t2 * bb;
+                            HH(j, k) = a - sum;
+                            HH(j, k + 1) = bb - sum * cv2;
+                        }
+                    }
+                    ctx.sync();
+                }
+                if (stats && tid == 0) { stats->intervals += T; stats->batches++; }
+            }
+            // ---- ensure H(i, i-1) is real
+            {
+                cd temp = HH(i, i - 1);
+                ctx.sync();
+                if (temp.y != 0.0) {
+                    const double rt = cabs(temp);
+                    if (tid == 0) HH(i, i - 1) = mk(rt, 0.0);
+                    temp = mk(temp.x / rt, temp.y / rt);
+                    for (int r = l + tid; r <= i - 1; r += nt) HH(r, i) = HH(r, i) * temp;
+                    ctx.sync();
+                }
+            }
+        }
+        ctx.sync();
+        if (done == 1) {
+            if (tid == 0) w[i] = HH(i, i);
+            i = l - 1;
+        } else if (done == 2) {
+            i = l - 1;
+        } else {
+            fail = 1;
+            for (int r = l + tid; r <= i; r += nt) w[r] = HH(r, r);
+            i = l - 1;
+        }
+        kdefl = 0;
+        ctx.sync();
+    }
+    if (tid == 0) *info = fail;
+    ctx.sync();
+#undef HH
+}
+
+}  // namespace kb

@@ -10,9 +10,7 @@ namespace kb {
 //   P : P (right accumulation) -> W (reduced matrix, then Hessenberg + reflectors) -> G = Dsqi Qh X
 //   R : R (sorted right vectors)
 //   H : Hessenberg work copy for the QR iteration -> X (eigenvectors in the Hessenberg basis)
-//   T : transposed Hessenberg copy (rows of H contiguous) for the inverse iteration
-//   UT: ut_waves x (l x l) LU workspaces of the inverse iteration
-enum { KB_BUF_A = 0, KB_BUF_Q, KB_BUF_P, KB_BUF_R, KB_BUF_H, KB_BUF_T, KB_BUF_UT, KB_NBUF };
+enum { KB_BUF_A = 0, KB_BUF_Q, KB_BUF_P, KB_BUF_R, KB_BUF_H, KB_NBUF };
 
 // Per-item vector arena (doubles), slot s starts at voff + s * vstride.
 enum {
@@ -27,7 +25,7 @@ enum {
 };
 
 struct KbItem {
-    int m, l, sig, ut_waves;
+    int m, l, sig, pad0;
     long long off[KB_NBUF];   // element (complex) offsets into the matrix arena
     long long voff;           // double offset into the vector arena
     int vstride, pad;

@@ -39,7 +39,6 @@ int env_int(const char* name, int def) {
 }
 
 constexpr int LDS_MAX = 160 * 1024;
-constexpr int UT_WAVES_MAX = 8;
 
 const char* kStageNames[KBDM_NSTAGES] = {"k_hankel", "k_svd_fac", "k_bdsqr",  "k_gemm<1>", "k_gemm<2>", "k_hess",
                                          "k_hqr",    "k_invit",   "k_gemm<3>", "k_gemm<4>", "k_gemm<5>", "k_epilogue"};
@@ -52,7 +51,8 @@ struct kbdm_ctx {
     int nt_fac = 1024;    // threads per workgroup: bidiagonalisation / Hessenberg kernels
     int nt_bdsqr = 1024;
     int nt_hqr = 256;
-    int nt_invit = 512;
+    int nt_invit = 1024;
+    int ns_hqr = 16;      // simultaneous shifts (bulges) of the QR iteration
     double ws_budget_gib = 96.0;
 };
 
@@ -88,10 +88,9 @@ struct kbdm_plan {
 
 namespace {
 
-size_t item_arena_elems(int m, int l, int ut_waves) {
-    const size_t M = (size_t)m * m, L2 = (size_t)l * l;
-    // A, Q, P, R, H : m*m each;  T : l*l;  UT : ut_waves * l*l
-    return 5 * M + L2 + (size_t)ut_waves * L2;
+size_t item_arena_elems(int m, int l) {
+    (void)l;
+    return 5 * (size_t)m * m;   // A, Q, P, R, H : m*m each
 }
 
 int set_lds_attr() {
@@ -111,7 +110,6 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
     pl->items.resize(B);
     pl->line_off.assign(B + 1, 0);
     pl->sv_off.assign(B + 1, 0);
-    const int ut_waves = std::min(UT_WAVES_MAX, ctx->nt_invit / 64);
     int64_t hk = 0;
     for (int i = 0; i < B; ++i) {
         KbItem& it = pl->items[i];
@@ -119,7 +117,6 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
         it.m = m[i];
         it.l = l ? l[i] : m[i];
         it.sig = sig_idx ? sig_idx[i] : 0;
-        it.ut_waves = ut_waves;
         it.q = pl->q;
         if (it.m < 1 || it.l < 1 || it.l > it.m) return fail(KBDM_E_INVALID, "item with invalid m/l");
         if (pl->N > 0 && (2 * it.m + pl->p - 1 > pl->N || it.sig < 0 || it.sig >= pl->S))
@@ -147,7 +144,7 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
     pl->varena_elems = 0;
     for (int pos = 0; pos < B; ++pos) {
         KbItem& it = pl->items[pl->perm[pos]];
-        const size_t need = item_arena_elems(it.m, it.l, it.ut_waves);
+        const size_t need = item_arena_elems(it.m, it.l);
         if (need > budget) return fail(KBDM_E_NOMEM, "one item exceeds the workspace budget");
         if (cur.count > 0 && used + need > budget) {
             pl->chunks.push_back(cur);
@@ -156,15 +153,13 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
             used = 0;
             vused = 0;
         }
-        const size_t M = (size_t)it.m * it.m, L2 = (size_t)it.l * it.l;
+        const size_t M = (size_t)it.m * it.m;
         size_t o = used;
         it.off[KB_BUF_A] = o; o += M;
         it.off[KB_BUF_Q] = o; o += M;
         it.off[KB_BUF_P] = o; o += M;
         it.off[KB_BUF_R] = o; o += M;
         it.off[KB_BUF_H] = o; o += M;
-        it.off[KB_BUF_T] = o; o += L2;
-        it.off[KB_BUF_UT] = o; o += (size_t)it.ut_waves * L2;
         used = o;
         it.vstride = (it.m + 1) & ~1;
         it.voff = (long long)vused;
@@ -252,15 +247,14 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
-        const int sm = KB_RED_BYTES + 64;
+        const int sm = KB_RED_BYTES + hqr_ms_scratch_bytes(KB_MS_NSMAX);
         hipLaunchKernelGGL(k_hqr, dim3(ch.count), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, pl->d_mu, pl->d_status, sm);
+                           pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
         const int per = invit_scratch_bytes_per_wave(ch.lmax);
-        int nw = std::min(ctx->nt_invit / 64, UT_WAVES_MAX);
-        nw = std::min(nw, (LDS_MAX - 64 - KB_RED_BYTES) / per);
+        int nw = std::min(ctx->nt_invit / 64, (LDS_MAX - 64 - KB_RED_BYTES) / per);
         if (nw < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
         const int sm = KB_RED_BYTES + nw * per;
         hipLaunchKernelGGL(k_invit, dim3(ch.count), dim3(ctx->nt_invit), sm, st, pl->d_items, perm, pl->d_arena,
@@ -310,6 +304,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->nt_bdsqr = env_int("KBDM_NT_BDSQR", c->nt_bdsqr);
     c->nt_hqr = env_int("KBDM_NT_HQR", c->nt_hqr);
     c->nt_invit = env_int("KBDM_NT_INVIT", c->nt_invit);
+    c->ns_hqr = env_int("KBDM_NS_HQR", c->ns_hqr);
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
     int r = set_lds_attr();
     if (r) { delete c; return r; }

@@ -9,7 +9,7 @@
 //   k_gemm<1>  T1 = U^p R_        (U^p read straight from the signal: Hankel operand)
 //   k_gemm<2>  W  = Dsqi L_^H T1 Dsqi                               (kbdm.py:168-189)
 //   k_hess     Hessenberg reduction + Qh + copies                   (kbdm.py:192)
-//   k_hqr      eigenvalues (active-block single-shift QR)           (kbdm.py:192)
+//   k_hqr      eigenvalues (active-block multi-bulge QR)            (kbdm.py:192)
 //   k_invit    eigenvectors by inverse iteration                    (kbdm.py:192)
 //   k_gemm<3>  G  = Dsqi (Qh X)                                     (kbdm.py:198)
 //   k_gemm<4>  B  = R_ G                                            (kbdm.py:198)
@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kb_eig.hpp"
+#include "kb_hqr_ms.hpp"
 #include "kb_svd.hpp"
 #include "kbdm_device.h"
 
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, 
 
 // ------------------------------------------------------------------------------------
 // Hessenberg reduction of W (in KB_BUF_P), Qh -> KB_BUF_Q, work copy -> KB_BUF_H,
-// transposed copy -> KB_BUF_T, ||H||_inf -> varena.
+// ||H||_inf -> varena.
 __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                 cd* arena, double* varena, int smem_bytes) {
     const KbItem it = items[perm[blockIdx.x]];
@@ -230,12 +231,11 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
     cd* W = arena + it.off[KB_BUF_P];
     cd* Qh = arena + it.off[KB_BUF_Q];
     cd* Hc = arena + it.off[KB_BUF_H];
-    cd* Ht = arena + it.off[KB_BUF_T];
     double* dv = varena + it.voff;
     cd* tauh = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);   // tauq is dead by now
     gehd2(ctx, n, W, n, tauh);
     gen_qh(ctx, n, W, n, tauh, Qh, n);
-    hess_copies(ctx, n, W, n, Hc, n, Ht, n);
+    hess_copy(ctx, n, W, n, Hc, n);
     double rmax = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         double r = 0.0;
@@ -249,14 +249,14 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
 
 __global__ void __launch_bounds__(1024) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                cd* arena, double* varena, cd* mu_out, int* status,
-                                               int smem_bytes) {
+                                               int smem_bytes, int nsmax) {
     const int item = perm[blockIdx.x];
     const KbItem it = items[item];
     const DevCtx ctx = make_ctx(smem_bytes);
     cd* Hc = arena + it.off[KB_BUF_H];
     cd* mu = mu_out + it.line_off;
     __shared__ int info;
-    hqr_eigvals(ctx, it.l, Hc, it.l, mu, &info);
+    hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax);
     if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
 }
 
@@ -267,17 +267,15 @@ __global__ void __launch_bounds__(1024) k_invit(const KbItem* __restrict__ items
     const KbItem it = items[item];
     const DevCtx ctx = make_ctx(smem_bytes);
     const int n = it.l;
-    const cd* Ht = arena + it.off[KB_BUF_T];
+    const cd* Hw = arena + it.off[KB_BUF_P];     // H above the Householder vectors of k_hess
     cd* X = arena + it.off[KB_BUF_H];
-    cd* UT = arena + it.off[KB_BUF_UT];
     const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
     int nw = ctx.scratch_bytes() / invit_scratch_bytes_per_wave(n);
     if (nw > ctx.nwaves()) nw = ctx.nwaves();
-    if (nw > it.ut_waves) nw = it.ut_waves;
     __shared__ int weak;
     if (threadIdx.x == 0) weak = 0;
     __syncthreads();
-    invit(ctx, n, Ht, n, mu_out + it.line_off, hnorm, UT, X, n, nw, &weak);
+    invit<DevCtx, 8>(ctx, n, Hw, n, mu_out + it.line_off, hnorm, X, n, nw, &weak);
     __syncthreads();
     if (threadIdx.x == 0 && weak) status[item] |= KB_STAT_INVIT_WEAK;
 }

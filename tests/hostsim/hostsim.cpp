@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kb_eig.hpp"
+#include "kb_hqr_ms.hpp"
 #include "kb_svd.hpp"
 
 using namespace kb;
@@ -58,13 +59,14 @@ int hs_bidiag(const double* A_in, int m, double* d, double* e, double* Q_out, do
 
 // W (n x n column-major) -> mu (n), P (n x n, column k = eigenvector of mu[k])
 int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
-    std::vector<cd> W(n * n), Qh(n * n), Hc(n * n), Ht(n * n), X(n * n), UT((size_t)n * n), th(n);
+    std::vector<cd> W(n * n), Qh(n * n), Hc(n * n), Ht(n * n), X(n * n), th(n);
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n));
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n) +
+                                      hqr_ms_scratch_bytes(KB_MS_NSMAX));
     gehd2(ctx, n, W.data(), n, th.data());
     gen_qh(ctx, n, W.data(), n, th.data(), Qh.data(), n);
-    hess_copies(ctx, n, W.data(), n, Hc.data(), n, Ht.data(), n);
+    hess_copy(ctx, n, W.data(), n, Hc.data(), n);
     // infinity norm of H (zhsein: hnorm = zlanhs('I'))
     double hnorm = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -74,8 +76,8 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     }
     int info = 0, weak = 0;
     cd* mu = reinterpret_cast<cd*>(mu_out);
-    hqr_eigvals(ctx, n, Hc.data(), n, mu, &info);
-    invit(ctx, n, Ht.data(), n, mu, hnorm, UT.data(), X.data(), n, 1, &weak);
+    hqr_eigvals_ms(ctx, n, Hc.data(), n, mu, &info, 16);   // the variant the k_hqr kernel runs
+    invit<HostCtx, 4096>(ctx, n, W.data(), n, mu, hnorm, X.data(), n, 1, &weak);
     // P = Qh * X
     cd* P = reinterpret_cast<cd*>(P_out);
     for (int j = 0; j < n; ++j)
@@ -87,6 +89,21 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     return info | (weak ? 4 : 0);
 }
 
+
+// eigenvalues only, multishift variant; stats = {intervals, batches, single_sweeps}
+int hs_eigvals_ms(const double* W_in, int n, int nsmax, double* mu_out, long long* stats_out) {
+    std::vector<cd> W(n * n), Hc(n * n), Ht(n * n), th(n);
+    memcpy(W.data(), W_in, sizeof(cd) * n * n);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_ms_scratch_bytes(nsmax));
+    gehd2(ctx, n, W.data(), n, th.data());
+    hess_copy(ctx, n, W.data(), n, Hc.data(), n);
+    int info = 0;
+    MsStats st = {0, 0, 0, 0};
+    hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st);
+    if (stats_out) { stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; }
+    return info;
+}
 
 // Full single-member pipeline (reference kbdm.py:19-92) with the host context.
 //   signal: N complex; lines: l x 4 row-major (A, T2, F, PH); sv: m; mu: l complex
