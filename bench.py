@@ -36,11 +36,15 @@ def stage_flops(m, l):
     m, l = float(m), float(l)
     return {
         "k_hankel": 0.0,
-        "k_svd_fac": (64.0 / 3.0) * m ** 3,          # bidiagonalisation 32/3 + Q,P generation 32/3
-        "k_bdsqr": (84.0 - 64.0 / 3.0) * m ** 3,     # remainder of the 84 m^3 SVD budget
+        "k_svd_fac": (32.0 / 3.0) * m ** 3,          # Householder bidiagonalisation
+        "k_gen(Q,P)": (32.0 / 3.0) * m ** 3,         # explicit Q and P
+        "k_bdsqr_gen": 0.0,                          # O(m^2) scalar recurrence
+        "k_bdsqr_apply": (84.0 - 64.0 / 3.0) * m ** 3,   # remainder of the 84 m^3 SVD budget
+        "k_bdsqr_sort": 0.0,
         "k_gemm<1>": 8.0 * m * m * l,
         "k_gemm<2>": 8.0 * l * l * m,
-        "k_hess": (56.0 / 3.0) * l ** 3,             # Hessenberg 40/3 + Qh 16/3
+        "k_hess": (40.0 / 3.0) * l ** 3,             # Hessenberg reduction
+        "k_gen(Qh)": (16.0 / 3.0) * l ** 3,          # explicit Qh
         "k_hqr": (100.0 - 56.0 / 3.0 - 16.0) * l ** 3,
         "k_invit": 8.0 * l ** 3,
         "k_gemm<3>": 8.0 * l ** 3,

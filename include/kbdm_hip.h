@@ -47,7 +47,7 @@ extern "C" {
 #define KBDM_STAT_INVIT_WEAK 4
 
 /* number of per-stage timers reported by kbdm_plan_stage_ms */
-#define KBDM_NSTAGES 12
+#define KBDM_NSTAGES 16
 
 typedef struct kbdm_ctx kbdm_ctx;
 typedef struct kbdm_plan kbdm_plan;

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libkbdm_hip.so")
 
 KBDM_ABI_VERSION = 1
-KBDM_NSTAGES = 12
+KBDM_NSTAGES = 16
 STAT_SVD_NOCONV, STAT_EIG_NOCONV, STAT_INVIT_WEAK = 1, 2, 4
 
 # every symbol include/kbdm_hip.h declares: (restype, argtypes)

@@ -51,23 +51,6 @@ KB_HD void gehd2(const C& ctx, int n, cd* W, int ld, cd* tauh) {
     }
 }
 
-// Qh = H_0 ... H_{n-3} explicit (n x n); reflectors act on indices >= 1.
-template <class C>
-KB_HD void gen_qh(const C& ctx, int n, const cd* W, int ld, const cd* tauh, cd* Q, int ldq) {
-    for (int idx = ctx.tid(); idx < n * n; idx += ctx.nthreads()) {
-        const int i = idx % n, j = idx / n;
-        Q[i + (size_t)j * ldq] = (i == j) ? mk(1.0, 0.0) : czero();
-    }
-    ctx.sync();
-    for (int k = n - 3; k >= 0; --k) {
-        const cd tau = tauh[k];
-        const int nv = n - k - 1;
-        if (!is_zero(tau))
-            apply_left(ctx, nv, nv, &W[(k + 1) + (size_t)k * ld], tau, &Q[(k + 1) + (size_t)(k + 1) * ldq], ldq);
-        ctx.sync();
-    }
-}
-
 // Extract the upper Hessenberg part of W into the work copy Hc that the QR iteration destroys
 // (W itself keeps H above its Householder vectors and later feeds the inverse iteration).
 template <class C>
@@ -317,7 +300,7 @@ KB_HD int invit_scratch_bytes_per_wave(int n) { return (3 * n + 2) * (int)sizeof
 
 template <class C, int MAXC>
 KB_HD void invit(const C& ctx, int n, const cd* H, int ldh, const cd* w, double hnorm, cd* X, int ldx,
-                 int nwaves_used, int* weak) {
+                 int nwaves_used, int* weak, int part = 0, int nparts = 1) {
     const int lane = ctx.lane();
     const double eps3 = fmax(hnorm * KB_ULP, KB_SAFMIN * ((double)n / KB_ULP));
     const double rootn = sqrt((double)n);
@@ -330,7 +313,7 @@ KB_HD void invit(const C& ctx, int n, const cd* H, int ldh, const cd* w, double 
                          (size_t)nwaves_used * (3 * n + 2) * sizeof(cd) + (size_t)ctx.wave() * n;
     const bool fast = (n <= MAXC * C::WS);
     int nweak = 0;
-    for (int kk = ctx.wave(); kk < n; kk += nwaves_used) {
+    for (int kk = part * nwaves_used + ctx.wave(); kk < n; kk += nparts * nwaves_used) {
         cd wk = w[kk];
         {
             int cnt = 0;

@@ -18,6 +18,8 @@ namespace kb {
 
 constexpr int KB_MS_MIN = 12;     // below this active size: single-shift sweeps
 constexpr int KB_MS_NSMAX = 32;   // compile-time cap on simultaneous shifts
+constexpr int KB_MS_BU = 4;       // bulges whose loads are batched together
+constexpr int KB_MS_CU = 2;       // row/column chunks per thread batched together
 
 // The lanes of ONE wavefront presented as a tiny workgroup (for the small shift solver).
 template <class C>
@@ -181,9 +183,313 @@ KB_HD void single_shift_sweep(const C& ctx, cd* H, int ld, int l, int i, int kde
 #undef HH
 }
 
+// Unblocked multi-bulge chase: every interval works directly on H in global memory.
+template <class C>
+KB_HD void chase_global(const C& ctx, cd* H, int ld, int l, int i, int ns, const cd* sh, MsRefl* refl) {
+#define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
+    const int tid = ctx.tid(), nt = ctx.nthreads();
+    const int na = i - l + 1;
+    const int T = (na - 1) + 3 * (ns - 1);
+    for (int t = 0; t < T; ++t) {
+        // active bulges: 0 <= t - 3b <= na - 2
+        int b_hi = t / 3;
+        if (b_hi > ns - 1) b_hi = ns - 1;
+        int b_lo = (t - (na - 2) + 2) / 3;
+        if (t - (na - 2) <= 0) b_lo = 0;
+        // phase 0: reflectors (one thread per bulge)
+        for (int b = b_lo + tid; b <= b_hi; b += nt) {
+            const int k = l + t - 3 * b;
+            cd v1, v2, t1;
+            if (k == l) {
+                cd h11s = HH(l, l) - sh[b];
+                const cd h21 = HH(l + 1, l);
+                const double s = cabs1(h11s) + cabs1(h21);
+                if (s == 0.0) { v1 = czero(); v2 = czero(); }
+                else { v1 = mk(h11s.x / s, h11s.y / s); v2 = mk(h21.x / s, h21.y / s); }
+            } else {
+                v1 = HH(k, k - 1);
+                v2 = HH(k + 1, k - 1);
+            }
+            larfg2(v1, v2, t1);
+            if (k > l) { HH(k, k - 1) = v1; HH(k + 1, k - 1) = czero(); }
+            refl[b].t1 = t1; refl[b].v2 = v2; refl[b].t2 = t1 * v2; refl[b].k = k;
+        }
+        ctx.sync();
+        // phase R: rows k, k+1 ; columns k..i.  Loads of a whole group of bulges are
+        // issued before any store (different bulges touch different rows), so the
+        // global-memory round trips overlap instead of serialising.
+        for (int b0 = b_lo; b0 <= b_hi; b0 += KB_MS_BU) {
+            const int span = i - refl[(b0 + KB_MS_BU - 1 <= b_hi) ? b0 + KB_MS_BU - 1 : b_hi].k + 1;
+            for (int c0 = 0; c0 < span; c0 += KB_MS_CU * nt) {
+                cd va[KB_MS_BU][KB_MS_CU], vb[KB_MS_BU][KB_MS_CU];
+#pragma unroll
+                for (int u = 0; u < KB_MS_BU; ++u) {
+                    const int b = b0 + u;
+                    const int k = (b <= b_hi) ? refl[b].k : 0;
+#pragma unroll
+                    for (int v = 0; v < KB_MS_CU; ++v) {
+                        const int j = k + c0 + v * nt + tid;
+                        if (b <= b_hi && j <= i) { va[u][v] = HH(k, j); vb[u][v] = HH(k + 1, j); }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KB_MS_BU; ++u) {
+                    const int b = b0 + u;
+                    if (b <= b_hi) {
+                        const MsRefl rf = refl[b];
+                        const int k = rf.k;
+                        const cd ct1 = conj(rf.t1), ct2 = conj(rf.t2);
+#pragma unroll
+                        for (int v = 0; v < KB_MS_CU; ++v) {
+                            const int j = k + c0 + v * nt + tid;
+                            if (j <= i) {
+                                const cd sum = ct1 * va[u][v] + ct2 * vb[u][v];
+                                HH(k, j) = va[u][v] - sum;
+                                HH(k + 1, j) = vb[u][v] - sum * rf.v2;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        ctx.sync();
+        // phase C: columns k, k+1 ; rows l..min(k+2, i)
+        for (int b0 = b_lo; b0 <= b_hi; b0 += KB_MS_BU) {
+            const int kmax = refl[b0].k;     // bulge b0 is the lowest of its group
+            const int span = ((kmax + 2 < i) ? kmax + 2 : i) - l + 1;
+            for (int c0 = 0; c0 < span; c0 += KB_MS_CU * nt) {
+                cd va[KB_MS_BU][KB_MS_CU], vb[KB_MS_BU][KB_MS_CU];
+#pragma unroll
+                for (int u = 0; u < KB_MS_BU; ++u) {
+                    const int b = b0 + u;
+                    const int k = (b <= b_hi) ? refl[b].k : 0;
+                    const int rmax = (k + 2 < i) ? k + 2 : i;
+#pragma unroll
+                    for (int v = 0; v < KB_MS_CU; ++v) {
+                        const int j = l + c0 + v * nt + tid;
+                        if (b <= b_hi && j <= rmax) { va[u][v] = HH(j, k); vb[u][v] = HH(j, k + 1); }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KB_MS_BU; ++u) {
+                    const int b = b0 + u;
+                    if (b <= b_hi) {
+                        const MsRefl rf = refl[b];
+                        const int k = rf.k;
+                        const int rmax = (k + 2 < i) ? k + 2 : i;
+                        const cd cv2 = conj(rf.v2);
+#pragma unroll
+                        for (int v = 0; v < KB_MS_CU; ++v) {
+                            const int j = l + c0 + v * nt + tid;
+                            if (j <= rmax) {
+                                const cd sum = rf.t1 * va[u][v] + rf.t2 * vb[u][v];
+                                HH(j, k) = va[u][v] - sum;
+                                HH(j, k + 1) = vb[u][v] - sum * cv2;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        ctx.sync();
+    }
+#undef HH
+}
+
+// ---------------------------------------------------------------------------------
+// Windowed multi-bulge chase.
+//
+// The unblocked chase moves every row/column of the active block through the CU once per
+// interval (n + 3 ns intervals per batch); with H in HBM/L2 that traffic - row accesses are
+// strided - is what bounds k_hqr.  Here the intervals are grouped into window steps.  In one
+// step the bulge chain moves d = W - 3 ns - 1 rows down inside a W x W diagonal window that
+// lives in LDS; every reflector is applied immediately inside the window and only LOGGED for
+// the rest of the active block.  After the step the log is replayed on
+//   * the right strip  H[ws:we, we:i]   (row operations, one lane per column)
+//   * the top strip    H[l:ws, ws:we]   (column operations, one lane per row)
+// from LDS tiles: each strip element is read and written once per window step, and the
+// replay keeps one operand in a register (bulge-major order: reflectors of different bulges
+// act on disjoint rows whenever their time order is swapped, so they commute).
+KB_HD int hqr_win_scratch_bytes(int nsmax, int W) {
+    // shift solver area + reflector table (hqr_ms_scratch_bytes), window image, second tile, log
+    const int logcap = (W + 2) * nsmax;
+    return hqr_ms_scratch_bytes(nsmax) + 2 * W * (W + 1) * (int)sizeof(cd) + logcap * (int)sizeof(MsRefl) + 128;
+}
+
+template <class C>
+KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, const cd* sh, MsRefl* refl,
+                          int W, int nsmax, MsStats* stats) {
+#define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
+#define HW(i_, j_) Hw[((i_) - ws) + ((j_) - ws) * WP]
+    const int tid = ctx.tid(), nt = ctx.nthreads();
+    const int na = i - l + 1;
+    const int WP = W + 1;                                   // padded pitch of the LDS images
+    // scratch carve (after the areas hqr_eigvals_ms already uses: S, sh, refl, sinfo)
+    char* base = reinterpret_cast<char*>(refl + nsmax) + 64;   // past refl[nsmax] and the info word
+    cd* Hw = reinterpret_cast<cd*>(base);
+    cd* Tile = Hw + (size_t)W * WP;
+    MsRefl* logv = reinterpret_cast<MsRefl*>(Tile + (size_t)W * WP);
+    const int T = (na - 1) + 3 * (ns - 1);
+    int t0 = 0;
+    while (t0 < T) {
+        // ---- window of this step: first row = row above the topmost active bulge
+        int bh0 = t0 / 3;
+        if (bh0 > ns - 1) bh0 = ns - 1;
+        const int kmin0 = l + t0 - 3 * bh0;
+        int ws = kmin0 - 1;
+        if (ws < l) ws = l;
+        int we = ws + W;                                    // exclusive
+        if (we > i + 1) we = i + 1;
+        // ---- how many intervals fit: lowest bulge must keep k+2 inside the window
+        int t1 = t0;
+        for (; t1 < T; ++t1) {
+            int blo = 0;
+            if (t1 - (na - 2) > 0) blo = (t1 - (na - 2) + 2) / 3;
+            const int kmax = l + t1 - 3 * blo;
+            const int reach = (kmax + 2 < i) ? kmax + 2 : i;
+            if (reach > we - 1) break;
+            int bhi = t1 / 3;
+            if (bhi > ns - 1) bhi = ns - 1;
+            const int kmin = l + t1 - 3 * bhi;
+            if (kmin > l && kmin - 1 < ws) break;           // cannot happen (kmin never decreases below ws+1)
+        }
+        if (t1 == t0) t1 = t0 + 1;     // unreachable for W >= 3 ns + 8; never spin
+        const int nint = t1 - t0;
+        int bmin = 0;
+        if (t0 - (na - 2) > 0) bmin = (t0 - (na - 2) + 2) / 3;
+        int bmax = (t1 - 1) / 3;
+        if (bmax > ns - 1) bmax = ns - 1;
+        // log, bulge-major: entry (b - bmin) * nint + (t - t0); k < 0 marks "not active"
+        for (int idx = tid; idx < (bmax - bmin + 1) * nint; idx += nt) logv[idx].k = -1;
+        // ---- (a) load the diagonal window
+        const int wlen = we - ws;
+        for (int idx = tid; idx < wlen * wlen; idx += nt) {
+            const int r = idx % wlen, c = idx / wlen;
+            Hw[r + c * WP] = HH(ws + r, ws + c);
+        }
+        ctx.sync();
+        // ---- (b) chase inside the window, logging the reflectors
+        for (int t = t0; t < t1; ++t) {
+            int b_hi = t / 3;
+            if (b_hi > ns - 1) b_hi = ns - 1;
+            int b_lo = 0;
+            if (t - (na - 2) > 0) b_lo = (t - (na - 2) + 2) / 3;
+            for (int b = b_lo + tid; b <= b_hi; b += nt) {
+                const int k = l + t - 3 * b;
+                cd v1, v2, t1c;
+                if (k == l) {
+                    cd h11s = HW(l, l) - sh[b];
+                    const cd h21 = HW(l + 1, l);
+                    const double sc = cabs1(h11s) + cabs1(h21);
+                    if (sc == 0.0) { v1 = czero(); v2 = czero(); }
+                    else { v1 = mk(h11s.x / sc, h11s.y / sc); v2 = mk(h21.x / sc, h21.y / sc); }
+                } else {
+                    v1 = HW(k, k - 1);
+                    v2 = HW(k + 1, k - 1);
+                }
+                larfg2(v1, v2, t1c);
+                if (k > l) { HW(k, k - 1) = v1; HW(k + 1, k - 1) = czero(); }
+                MsRefl rf;
+                rf.t1 = t1c; rf.v2 = v2; rf.t2 = t1c * v2; rf.k = k; rf.pad = b;
+                refl[b] = rf;
+                logv[(b - bmin) * nint + (t - t0)] = rf;
+            }
+            ctx.sync();
+            const int nb = b_hi - b_lo + 1;
+            // rows k, k+1 ; columns k..min(i, we-1)
+            const int cmax = (i < we - 1) ? i : we - 1;
+            for (int idx = tid; idx < nb * W; idx += nt) {
+                const int b = b_lo + idx / W;
+                const MsRefl rf = refl[b];
+                const int j = rf.k + idx % W;
+                if (j <= cmax) {
+                    const cd a = HW(rf.k, j), bb = HW(rf.k + 1, j);
+                    const cd sum = conj(rf.t1) * a + conj(rf.t2) * bb;
+                    HW(rf.k, j) = a - sum;
+                    HW(rf.k + 1, j) = bb - sum * rf.v2;
+                }
+            }
+            ctx.sync();
+            // columns k, k+1 ; rows ws'..min(k+2, i)   (ws' = max(l, ws) = ws)
+            for (int idx = tid; idx < nb * W; idx += nt) {
+                const int b = b_lo + idx / W;
+                const MsRefl rf = refl[b];
+                const int rmax = (rf.k + 2 < i) ? rf.k + 2 : i;
+                const int r = ws + idx % W;
+                if (r <= rmax) {
+                    const cd a = HW(r, rf.k), bb = HW(r, rf.k + 1);
+                    const cd sum = rf.t1 * a + rf.t2 * bb;
+                    HW(r, rf.k) = a - sum;
+                    HW(r, rf.k + 1) = bb - sum * conj(rf.v2);
+                }
+            }
+            ctx.sync();
+        }
+        // ---- (c) store the window back
+        for (int idx = tid; idx < wlen * wlen; idx += nt) {
+            const int r = idx % wlen, c = idx / wlen;
+            HH(ws + r, ws + c) = Hw[r + c * WP];
+        }
+        ctx.sync();
+        // Replay the log bulge-major.  Two LDS tiles (the window image is free now):
+        // wavefronts 0 and 1.
+        const int ntb = (ctx.nwaves() >= 2) ? 2 : 1;
+        // ---- (d) right strip: rows ws..we-1, columns we..i ; lanes = columns
+        // ---- (e) top strip:   rows l..ws-1,  columns ws..we-1 ; lanes = rows
+        const int nright = (we <= i) ? i - we + 1 : 0;
+        const int ntop = ws - l;
+        const int tiles_r = (nright + C::WS - 1) / C::WS, tiles_t = (ntop + C::WS - 1) / C::WS;
+        if (ctx.wave() < ntb) {
+            cd* Tl = (ctx.wave() == 0) ? Hw : Tile;
+            const int lane = ctx.lane();
+            for (int tile = ctx.wave(); tile < tiles_r + tiles_t; tile += ntb) {
+                const bool right = tile < tiles_r;
+                const int q0 = right ? we + tile * C::WS : l + (tile - tiles_r) * C::WS;
+                const int q = q0 + lane;
+                const bool live = right ? (q <= i) : (q < ws);
+                // load: Tl[p * WP + lane] = element p of this lane's column (right) / row (top)
+                if (live)
+                    for (int p = 0; p < wlen; ++p) Tl[p * WP + lane] = right ? HH(ws + p, q) : HH(q, ws + p);
+                ctx.wave_fence();
+                if (live) {
+                    for (int b = 0; b <= bmax - bmin; ++b) {
+                        bool have = false;
+                        cd carry = czero();
+                        int pc = 0;
+                        for (int tt = 0; tt < nint; ++tt) {
+                            const MsRefl rf = logv[b * nint + tt];
+                            if (rf.k < 0) continue;
+                            const int p = rf.k - ws;
+                            if (!have) { carry = Tl[p * WP + lane]; have = true; }
+                            const cd bb = Tl[(p + 1) * WP + lane];
+                            cd sum, bnew;
+                            if (right) { sum = conj(rf.t1) * carry + conj(rf.t2) * bb; bnew = bb - sum * rf.v2; }
+                            else { sum = rf.t1 * carry + rf.t2 * bb; bnew = bb - sum * conj(rf.v2); }
+                            Tl[p * WP + lane] = carry - sum;
+                            carry = bnew;
+                            pc = p + 1;
+                        }
+                        if (have) Tl[pc * WP + lane] = carry;
+                    }
+                    for (int p = 0; p < wlen; ++p) {
+                        if (right) HH(ws + p, q) = Tl[p * WP + lane];
+                        else HH(q, ws + p) = Tl[p * WP + lane];
+                    }
+                }
+                ctx.wave_fence();
+            }
+        }
+        ctx.sync();
+        if (stats && tid == 0) stats->small_steps++;
+        t0 = t1;
+    }
+#undef HW
+#undef HH
+}
+
 template <class C>
 KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, int nsmax,
-                          MsStats* stats = nullptr) {
+                          MsStats* stats = nullptr, int win_w = 0) {
 #define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
     const double ulp = KB_ULP;
     const double smlnum = KB_SAFMIN * ((double)n / ulp);
@@ -292,59 +598,10 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
                 ctx.sync();
                 // ---- pipelined chase of ns bulges, 3 rows apart
                 const int T = (na - 1) + 3 * (ns - 1);
-                for (int t = 0; t < T; ++t) {
-                    // active bulges: 0 <= t - 3b <= na - 2
-                    int b_hi = t / 3;
-                    if (b_hi > ns - 1) b_hi = ns - 1;
-                    int b_lo = (t - (na - 2) + 2) / 3;
-                    if (t - (na - 2) <= 0) b_lo = 0;
-                    // phase 0: reflectors (one thread per bulge)
-                    for (int b = b_lo + tid; b <= b_hi; b += nt) {
-                        const int k = l + t - 3 * b;
-                        cd v1, v2, t1;
-                        if (k == l) {
-                            cd h11s = HH(l, l) - sh[b];
-                            const cd h21 = HH(l + 1, l);
-                            const double s = cabs1(h11s) + cabs1(h21);
-                            if (s == 0.0) { v1 = czero(); v2 = czero(); }
-                            else { v1 = mk(h11s.x / s, h11s.y / s); v2 = mk(h21.x / s, h21.y / s); }
-                        } else {
-                            v1 = HH(k, k - 1);
-                            v2 = HH(k + 1, k - 1);
-                        }
-                        larfg2(v1, v2, t1);
-                        if (k > l) { HH(k, k - 1) = v1; HH(k + 1, k - 1) = czero(); }
-                        refl[b].t1 = t1; refl[b].v2 = v2; refl[b].t2 = t1 * v2; refl[b].k = k;
-                    }
-                    ctx.sync();
-                    // phase R: rows k, k+1 ; columns k..i
-                    for (int b = b_lo; b <= b_hi; ++b) {
-                        const MsRefl rf = refl[b];
-                        const int k = rf.k;
-                        const cd ct1 = conj(rf.t1), ct2 = conj(rf.t2);
-                        for (int j = k + tid; j <= i; j += nt) {
-                            const cd a = HH(k, j), bb = HH(k + 1, j);
-                            const cd sum = ct1 * a + ct2 * bb;
-                            HH(k, j) = a - sum;
-                            HH(k + 1, j) = bb - sum * rf.v2;
-                        }
-                    }
-                    ctx.sync();
-                    // phase C: columns k, k+1 ; rows l..min(k+2, i)
-                    for (int b = b_lo; b <= b_hi; ++b) {
-                        const MsRefl rf = refl[b];
-                        const int k = rf.k;
-                        const int rmax = (k + 2 < i) ? k + 2 : i;
-                        const cd cv2 = conj(rf.v2);
-                        for (int j = l + tid; j <= rmax; j += nt) {
-                            const cd a = HH(j, k), bb = HH(j, k + 1);
-                            const cd sum = rf.t1 * a + rf.t2 * bb;
-                            HH(j, k) = a - sum;
-                            HH(j, k + 1) = bb - sum * cv2;
-                        }
-                    }
-                    ctx.sync();
-                }
+                if (win_w >= 3 * ns + 8)
+                    chase_windowed(ctx, H, ld, l, i, ns, sh, refl, win_w, nsmax, stats);
+                else
+                    chase_global(ctx, H, ld, l, i, ns, sh, refl);
                 if (stats && tid == 0) { stats->intervals += T; stats->batches++; }
             }
             // ---- ensure H(i, i-1) is real

@@ -32,6 +32,8 @@ struct KbItem {
     long long line_off;       // offset of this item's lines / mu / keep (units: lines)
     long long sv_off;         // offset of this item's singular values
     long long hk_off;         // offset (complex elements) into dense per-item m*m outputs of the stage APIs
+    long long rot_off;        // offset (Rot entries) of this item's rotation log
+    long long hdr_off;        // offset (RotBatch entries) of this item's batch headers
     double q;
 };
 

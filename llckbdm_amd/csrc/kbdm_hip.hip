@@ -40,8 +40,9 @@ int env_int(const char* name, int def) {
 
 constexpr int LDS_MAX = 160 * 1024;
 
-const char* kStageNames[KBDM_NSTAGES] = {"k_hankel", "k_svd_fac", "k_bdsqr",  "k_gemm<1>", "k_gemm<2>", "k_hess",
-                                         "k_hqr",    "k_invit",   "k_gemm<3>", "k_gemm<4>", "k_gemm<5>", "k_epilogue"};
+const char* kStageNames[KBDM_NSTAGES] = {"k_hankel",  "k_svd_fac", "k_gen(Q,P)", "k_bdsqr_gen", "k_bdsqr_apply", "k_bdsqr_sort",
+                                         "k_gemm<1>", "k_gemm<2>", "k_hess",     "k_gen(Qh)",   "k_hqr",         "k_invit",
+                                         "k_gemm<3>", "k_gemm<4>", "k_gemm<5>",  "k_epilogue"};
 
 }  // namespace
 
@@ -52,7 +53,10 @@ struct kbdm_ctx {
     int nt_bdsqr = 1024;
     int nt_hqr = 256;
     int nt_invit = 1024;
-    int ns_hqr = 16;      // simultaneous shifts (bulges) of the QR iteration
+    int ns_hqr = 8;       // simultaneous shifts (bulges) of the QR iteration
+    int win_hqr = 60;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
+    int split_gen = 4;    // workgroups per item and matrix in k_gen
+    int split_invit = 4;  // workgroups per item in k_invit
     double ws_budget_gib = 96.0;
 };
 
@@ -71,7 +75,10 @@ struct kbdm_plan {
     std::vector<Chunk> chunks;
     std::vector<int64_t> line_off, sv_off;
     int64_t total_lines = 0, total_sv = 0;
-    size_t arena_elems = 0, varena_elems = 0;
+    size_t arena_elems = 0, varena_elems = 0, rot_elems = 0, hdr_elems = 0;
+    Rot* d_rot = nullptr;
+    RotBatch* d_hdr = nullptr;
+    int* d_iwork = nullptr;
     cd* d_signals = nullptr;
     KbItem* d_items = nullptr;
     int* d_perm = nullptr;
@@ -90,12 +97,15 @@ namespace {
 
 size_t item_arena_elems(int m, int l) {
     (void)l;
-    return 5 * (size_t)m * m;   // A, Q, P, R, H : m*m each
+    // A, Q, P, R, H : m*m complex each; rotation log (32 B per step) counted in complex units
+    return 5 * (size_t)m * m + 2 * (size_t)bdsqr_log_steps_cap(m) + (size_t)bdsqr_log_batches_cap(m);
 }
 
 int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svd_fac), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_gen), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_apply), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_sort), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -138,7 +148,7 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
     // chunks: consecutive sorted items whose workspace fits the budget
     const size_t budget = (size_t)(ctx->ws_budget_gib * 1024.0 * 1024.0 * 1024.0) / sizeof(cd);
     pl->chunks.clear();
-    size_t used = 0, vused = 0;
+    size_t used = 0, vused = 0, rused = 0, hused = 0, acct = 0;
     Chunk cur;
     pl->arena_elems = 0;
     pl->varena_elems = 0;
@@ -146,13 +156,17 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
         KbItem& it = pl->items[pl->perm[pos]];
         const size_t need = item_arena_elems(it.m, it.l);
         if (need > budget) return fail(KBDM_E_NOMEM, "one item exceeds the workspace budget");
-        if (cur.count > 0 && used + need > budget) {
+        if (cur.count > 0 && acct + need > budget) {
             pl->chunks.push_back(cur);
             cur = Chunk();
             cur.first = pos;
-            used = 0;
-            vused = 0;
+            used = 0; vused = 0; rused = 0; hused = 0; acct = 0;
         }
+        acct += need;
+        it.rot_off = (long long)rused; rused += (size_t)bdsqr_log_steps_cap(it.m);
+        it.hdr_off = (long long)hused; hused += (size_t)bdsqr_log_batches_cap(it.m);
+        pl->rot_elems = std::max(pl->rot_elems, rused);
+        pl->hdr_elems = std::max(pl->hdr_elems, hused);
         const size_t M = (size_t)it.m * it.m;
         size_t o = used;
         it.off[KB_BUF_A] = o; o += M;
@@ -187,6 +201,9 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_mu, sizeof(cd) * std::max<int64_t>(pl->total_lines, 1)));
     HIPCHK(hipMalloc(&pl->d_keep, std::max<int64_t>(pl->total_lines, 1)));
     HIPCHK(hipMalloc(&pl->d_status, sizeof(int) * B));
+    HIPCHK(hipMalloc(&pl->d_iwork, sizeof(int) * 4 * std::max(B, 1)));
+    HIPCHK(hipMalloc(&pl->d_rot, sizeof(Rot) * std::max<size_t>(pl->rot_elems, 1)));
+    HIPCHK(hipMalloc(&pl->d_hdr, sizeof(RotBatch) * std::max<size_t>(pl->hdr_elems, 1)));
     if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
     return KBDM_OK;
 }
@@ -213,6 +230,21 @@ struct StageTimer {
 
 int smem_fac(int n, int nt) { return KB_RED_BYTES + bidiag_scratch_bytes(n, nt / 64, 64); }
 
+// k_gen with the smallest register-chunk count that covers the largest item of the launch
+int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat) {
+    kbdm_ctx* ctx = pl->ctx;
+    const int* perm = pl->d_perm + ch.first;
+    dim3 grid(ctx->split_gen, ch.count, nmat), block(256);
+    const int chunks = (nmax + 63) / 64;
+    if (chunks <= 2) hipLaunchKernelGGL(k_gen<2>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 4) hipLaunchKernelGGL(k_gen<4>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 8) hipLaunchKernelGGL(k_gen<8>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 16) hipLaunchKernelGGL(k_gen<16>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 32) hipLaunchKernelGGL(k_gen<32>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else return fail(KBDM_E_NOMEM, "m larger than 2048 is not supported by k_gen");
+    return KBDM_OK;
+}
+
 int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     kbdm_ctx* ctx = pl->ctx;
     hipStream_t st = ctx->stream;
@@ -225,10 +257,34 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
-        const int sm = KB_RED_BYTES + std::max(bdsqr_scratch_bytes(ch.mmax), 4 * ch.mmax + 64);
+        int r = launch_gen(pl, ch, ch.mmax, 0, 2);
+        if (r) return r;
+        if (tm) { r = tm->mark(); if (r) return r; }
+    }
+    {
+        const int sm = KB_RED_BYTES + bdsqr_gen_scratch_bytes(ch.mmax);
         if (sm > LDS_MAX - 64) return fail(KBDM_E_NOMEM, "m too large for the bidiagonal QR scratch");
-        hipLaunchKernelGGL(k_bdsqr, dim3(ch.count), dim3(ctx->nt_bdsqr), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, pl->d_sv, pl->d_status, sm);
+        hipLaunchKernelGGL(k_bdsqr_gen, dim3(ch.count), dim3(64), sm, st, pl->d_items, perm, pl->d_varena, pl->d_hdr,
+                           pl->d_rot, pl->d_iwork, sm);
+        if (tm) { int r = tm->mark(); if (r) return r; }
+    }
+    {
+        // rows per wavefront: as many as fit LDS, at most 32 (two lanes per row: re / im)
+        int R = (LDS_MAX - 64 - KB_RED_BYTES) / ((ch.mmax + 1) * (int)sizeof(cd));
+        if (R < 1) return fail(KBDM_E_NOMEM, "m too large for the rotation replay");
+        if (R > 32) R = 32;
+        const int sm = KB_RED_BYTES + R * (ch.mmax + 1) * (int)sizeof(cd);
+        // smaller items get 32 rows per group out of the same LDS budget; grid.x covers the worst case
+        const int rmin = std::min(32, (sm - KB_RED_BYTES) / ((ch.mmax + 1) * (int)sizeof(cd)));
+        const int groups = (ch.mmax + rmin - 1) / rmin;
+        hipLaunchKernelGGL(k_bdsqr_apply, dim3(groups, ch.count, 2), dim3(64), sm, st, pl->d_items, perm, pl->d_arena,
+                           pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
+        if (tm) { int r = tm->mark(); if (r) return r; }
+    }
+    {
+        const int sm = KB_RED_BYTES + 4 * ch.mmax + 64;
+        hipLaunchKernelGGL(k_bdsqr_sort, dim3(ch.count), dim3(ctx->nt_bdsqr), sm, st, pl->d_items, perm, pl->d_arena,
+                           pl->d_varena, pl->d_sv, pl->d_status, pl->d_iwork, sm);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     HIPCHK(hipGetLastError());
@@ -247,9 +303,19 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
-        const int sm = KB_RED_BYTES + hqr_ms_scratch_bytes(KB_MS_NSMAX);
+        int r = launch_gen(pl, ch, ch.lmax, 1, 1);
+        if (r) return r;
+        if (tm) { r = tm->mark(); if (r) return r; }
+    }
+    {
+        int win = ctx->win_hqr;
+        int sm = KB_RED_BYTES + (win > 0 ? hqr_win_scratch_bytes(ctx->ns_hqr, win) : hqr_ms_scratch_bytes(ctx->ns_hqr));
+        if (sm > LDS_MAX - 64) {   // window does not fit LDS with this many shifts: unblocked chase
+            win = 0;
+            sm = KB_RED_BYTES + hqr_ms_scratch_bytes(ctx->ns_hqr);
+        }
         hipLaunchKernelGGL(k_hqr, dim3(ch.count), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr);
+                           pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
@@ -257,8 +323,8 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         int nw = std::min(ctx->nt_invit / 64, (LDS_MAX - 64 - KB_RED_BYTES) / per);
         if (nw < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
         const int sm = KB_RED_BYTES + nw * per;
-        hipLaunchKernelGGL(k_invit, dim3(ch.count), dim3(ctx->nt_invit), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, pl->d_mu, pl->d_status, sm);
+        hipLaunchKernelGGL(k_invit, dim3(ch.count, ctx->split_invit), dim3(ctx->nt_invit), sm, st, pl->d_items, perm,
+                           pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     HIPCHK(hipGetLastError());
@@ -305,6 +371,12 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->nt_hqr = env_int("KBDM_NT_HQR", c->nt_hqr);
     c->nt_invit = env_int("KBDM_NT_INVIT", c->nt_invit);
     c->ns_hqr = env_int("KBDM_NS_HQR", c->ns_hqr);
+    c->win_hqr = env_int("KBDM_WIN_HQR", c->win_hqr);
+    if (c->ns_hqr > KB_MS_NSMAX) c->ns_hqr = KB_MS_NSMAX;
+    if (c->win_hqr > 0 && c->win_hqr < 3 * c->ns_hqr + 8) c->win_hqr = 3 * c->ns_hqr + 8;
+    c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
+    c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
+    if (c->nt_hqr > 256) c->nt_hqr = 256;   // k_hqr is compiled for <= 256 threads (register budget)
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
     int r = set_lds_attr();
     if (r) { delete c; return r; }
@@ -336,7 +408,7 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     if (!pl) return KBDM_OK;
     hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
-    hipFree(pl->d_keep); hipFree(pl->d_status);
+    hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork); hipFree(pl->d_rot); hipFree(pl->d_hdr);
     for (auto& ch : pl->chunks)
         for (auto& e : ch.ev) hipEventDestroy(e);
     delete pl;

@@ -4,8 +4,10 @@
 //
 // Pipeline (reference kbdm.py:64-92 per member; sampling.py:52-70 over members):
 //   k_hankel   U^{p-1} from the shared signal                      (kbdm.py:95-130)
-//   k_svd_fac  bidiagonalisation + explicit Q, P                    (kbdm.py:166)
-//   k_bdsqr    bidiagonal QR + sort  -> L, s, R                     (kbdm.py:166)
+//   k_svd_fac  Householder bidiagonalisation                       (kbdm.py:166)
+//   k_gen      explicit Q, P (and later Qh), columns in registers  (kbdm.py:166,192)
+//   k_bdsqr_gen / _apply / _sort   bidiagonal QR: logged rotations, LDS-resident row replay,
+//              sort -> L, s, R                                      (kbdm.py:166)
 //   k_gemm<1>  T1 = U^p R_        (U^p read straight from the signal: Hankel operand)
 //   k_gemm<2>  W  = Dsqi L_^H T1 Dsqi                               (kbdm.py:168-189)
 //   k_hess     Hessenberg reduction + Qh + copies                   (kbdm.py:192)
@@ -70,28 +72,93 @@ __global__ void __launch_bounds__(256) k_hankel(const KbItem* __restrict__ items
 }
 
 // ------------------------------------------------------------------------------------
-// One workgroup per item: bidiagonalisation + Q + P.
+// One workgroup per item: Householder bidiagonalisation (left vectors stay in A, right
+// vectors go to the R buffer, which is free until the sort).
 __global__ void __launch_bounds__(1024) k_svd_fac(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                    cd* arena, double* varena, int smem_bytes) {
     const KbItem it = items[perm[blockIdx.x]];
     const DevCtx ctx = make_ctx(smem_bytes);
     const int m = it.m;
     cd* A = arena + it.off[KB_BUF_A];
-    cd* Q = arena + it.off[KB_BUF_Q];
-    cd* P = arena + it.off[KB_BUF_P];
+    cd* UR = arena + it.off[KB_BUF_R];
     double* dv = varena + it.voff;
     double* d = dv + KB_V_D * it.vstride;
     double* e = dv + KB_V_E * it.vstride;
     cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);
     cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride);
-    bidiag(ctx, m, A, m, d, e, tauq, taup);
-    gen_q(ctx, m, A, m, tauq, Q, m);
-    gen_p(ctx, m, A, m, taup, P, m);
+    bidiag(ctx, m, A, m, d, e, tauq, taup, UR, m);
 }
 
-__global__ void __launch_bounds__(1024) k_bdsqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                 cd* arena, double* varena, double* sv_out,
-                                                 int* status, int smem_bytes) {
+// Explicit unitary factors, columns spread over gridDim.x workgroups per item and matrix.
+//   mode 0: blockIdx.z = 0 -> Q (from A, tauq) into Q;  blockIdx.z = 1 -> P (from R buffer, taup) into P
+//   mode 1: Qh (from the Hessenberg vectors in P, tauh) into Q
+template <int MAXC>
+__global__ void __launch_bounds__(256) k_gen(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                              cd* arena, double* varena, int mode) {
+    const KbItem it = items[perm[blockIdx.y]];
+    const DevCtx ctx = make_ctx(0);
+    double* dv = varena + it.voff;
+    int n, nref, shift;
+    const cd* V;
+    const cd* tau;
+    cd* Out;
+    if (mode == 0 && blockIdx.z == 0) {
+        n = it.m; nref = n; shift = 0;
+        V = arena + it.off[KB_BUF_A]; tau = reinterpret_cast<const cd*>(dv + KB_V_TAUQ * it.vstride);
+        Out = arena + it.off[KB_BUF_Q];
+    } else if (mode == 0) {
+        n = it.m; nref = n - 1; shift = 1;
+        V = arena + it.off[KB_BUF_R]; tau = reinterpret_cast<const cd*>(dv + KB_V_TAUP * it.vstride);
+        Out = arena + it.off[KB_BUF_P];
+    } else {
+        n = it.l; nref = n - 2; shift = 1;
+        V = arena + it.off[KB_BUF_P]; tau = reinterpret_cast<const cd*>(dv + KB_V_TAUQ * it.vstride);
+        Out = arena + it.off[KB_BUF_Q];
+    }
+    if (n > MAXC * 64) return;                       // host picks MAXC from the largest item
+    const int cpw = (n + gridDim.x - 1) / gridDim.x;
+    const int c0 = blockIdx.x * cpw;
+    const int c1 = (c0 + cpw < n) ? c0 + cpw : n;
+    if (c0 >= n) return;
+    gen_unitary_cols<DevCtx, MAXC>(ctx, n, nref, shift, V, n, tau, Out, n, c0, c1);
+}
+
+// Bidiagonal QR iteration, part 1: one wavefront per item runs the scalar recurrence on
+// (d, e) in LDS and logs every plane rotation (iwork[4*item] = batches, [4*item+1] = info).
+__global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                   double* varena, RotBatch* hdr_all, Rot* rot_all, int* iwork,
+                                                   int smem_bytes) {
+    const int item = perm[blockIdx.x];
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    double* dv = varena + it.voff;
+    bdsqr_gen(ctx, it.m, dv + KB_V_D * it.vstride, dv + KB_V_E * it.vstride, hdr_all + it.hdr_off,
+              rot_all + it.rot_off, &iwork[4 * item], &iwork[4 * item + 1]);
+}
+
+// Part 2: the logged rotations are applied to the rows of Q (blockIdx.z = 0) and P (= 1).
+// One wavefront owns a group of rows, staged in LDS for the whole replay.
+__global__ void __launch_bounds__(64) k_bdsqr_apply(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                     cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
+                                                     const int* iwork, int smem_bytes) {
+    const int item = perm[blockIdx.y];
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const int m = it.m;
+    int R = ctx.scratch_bytes() / ((m + 1) * (int)sizeof(cd));
+    if (R > 32) R = 32;
+    const int row0 = blockIdx.x * R;
+    if (row0 >= m) return;
+    const int nrows = (row0 + R <= m) ? R : m - row0;
+    cd* X = arena + it.off[blockIdx.z == 0 ? KB_BUF_Q : KB_BUF_P];
+    bdsqr_apply_rows(ctx, m, X, m, row0, nrows, (int)blockIdx.z, hdr_all + it.hdr_off, rot_all + it.rot_off,
+                     iwork[4 * item]);
+}
+
+// Part 3: sign fix, descending sort, permuted copy into L (A buffer) and R, Dsqi, outputs.
+__global__ void __launch_bounds__(1024) k_bdsqr_sort(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                      cd* arena, double* varena, double* sv_out, int* status,
+                                                      const int* iwork, int smem_bytes) {
     const int item = perm[blockIdx.x];
     const KbItem it = items[item];
     const DevCtx ctx = make_ctx(smem_bytes);
@@ -102,11 +169,8 @@ __global__ void __launch_bounds__(1024) k_bdsqr(const KbItem* __restrict__ items
     cd* R = arena + it.off[KB_BUF_R];
     double* dv = varena + it.voff;
     double* d = dv + KB_V_D * it.vstride;
-    double* e = dv + KB_V_E * it.vstride;
     double* s = dv + KB_V_S * it.vstride;
     double* dsqi = dv + KB_V_DSQI * it.vstride;
-    __shared__ int info;
-    bdsqr(ctx, m, d, e, Q, m, P, m, &info);
     sort_sv(ctx, m, d, Q, m, P, m, s, L, m, R, m);
     // singular values out + the scaling Dsqi = 1/sqrt(s) (q = 0) or 1/sqrt(s + q^2/s)  [kbdm.py:179-186]
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
@@ -114,7 +178,7 @@ __global__ void __launch_bounds__(1024) k_bdsqr(const KbItem* __restrict__ items
         if (sv_out) sv_out[it.sv_off + i] = si;
         if (i < it.l) dsqi[i] = (it.q > 0.0) ? 1.0 / sqrt(si + it.q * it.q / si) : 1.0 / sqrt(si);
     }
-    if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_SVD_NOCONV;
+    if (threadIdx.x == 0 && iwork[4 * item + 1] != 0) status[item] |= KB_STAT_SVD_NOCONV;
 }
 
 // ------------------------------------------------------------------------------------
@@ -229,12 +293,10 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
     const DevCtx ctx = make_ctx(smem_bytes);
     const int n = it.l;
     cd* W = arena + it.off[KB_BUF_P];
-    cd* Qh = arena + it.off[KB_BUF_Q];
     cd* Hc = arena + it.off[KB_BUF_H];
     double* dv = varena + it.voff;
     cd* tauh = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);   // tauq is dead by now
     gehd2(ctx, n, W, n, tauh);
-    gen_qh(ctx, n, W, n, tauh, Qh, n);
     hess_copy(ctx, n, W, n, Hc, n);
     double rmax = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -247,16 +309,16 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
     if (threadIdx.x == 0) dv[KB_V_MISC * it.vstride] = rmax;
 }
 
-__global__ void __launch_bounds__(1024) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
+__global__ void __launch_bounds__(256) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                cd* arena, double* varena, cd* mu_out, int* status,
-                                               int smem_bytes, int nsmax) {
+                                               int smem_bytes, int nsmax, int win_w) {
     const int item = perm[blockIdx.x];
     const KbItem it = items[item];
     const DevCtx ctx = make_ctx(smem_bytes);
     cd* Hc = arena + it.off[KB_BUF_H];
     cd* mu = mu_out + it.line_off;
     __shared__ int info;
-    hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax);
+    hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, nullptr, win_w);
     if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
 }
 
@@ -275,9 +337,9 @@ __global__ void __launch_bounds__(1024) k_invit(const KbItem* __restrict__ items
     __shared__ int weak;
     if (threadIdx.x == 0) weak = 0;
     __syncthreads();
-    invit<DevCtx, 8>(ctx, n, Hw, n, mu_out + it.line_off, hnorm, X, n, nw, &weak);
+    invit<DevCtx, 8>(ctx, n, Hw, n, mu_out + it.line_off, hnorm, X, n, nw, &weak, blockIdx.y, gridDim.y);
     __syncthreads();
-    if (threadIdx.x == 0 && weak) status[item] |= KB_STAT_INVIT_WEAK;
+    if (threadIdx.x == 0 && weak) atomicOr(&status[item], KB_STAT_INVIT_WEAK);
 }
 
 // ------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@
 
 using namespace kb;
 typedef std::complex<double> zc;
+constexpr int HS_MAXC = 2048;   // host wave size is 1: one register chunk per row
 
 static HostCtx make_ctx(std::vector<char>& arena, size_t bytes) {
     arena.assign(bytes + KB_RED_BYTES + 64, 0);
@@ -30,16 +31,21 @@ extern "C" {
 
 // A (m x m column-major) -> L (m x m), s (m), R (m x m), A = L diag(s) R^H
 int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_out) {
-    std::vector<cd> A(m * m), Q(m * m), P(m * m), tq(m), tp(m);
+    std::vector<cd> A(m * m), Q(m * m), P(m * m), UR(m * m), tq(m), tp(m);
     std::vector<double> d(m), e(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_scratch_bytes(m, 1, 1) + bdsqr_scratch_bytes(m) + 4 * m);
-    bidiag(ctx, m, A.data(), m, d.data(), e.data(), tq.data(), tp.data());
-    gen_q(ctx, m, A.data(), m, tq.data(), Q.data(), m);
-    gen_p(ctx, m, A.data(), m, tp.data(), P.data(), m);
-    int info = 0;
-    bdsqr(ctx, m, d.data(), e.data(), Q.data(), m, P.data(), m, &info);
+    HostCtx ctx = make_ctx(arena, bidiag_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) +
+                                      bdsqr_apply_scratch_bytes(m, m) + 4 * m);
+    bidiag(ctx, m, A.data(), m, d.data(), e.data(), tq.data(), tp.data(), UR.data(), m);
+    gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
+    gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
+    int info = 0, nb = 0;
+    std::vector<RotBatch> hdr(bdsqr_log_batches_cap(m));
+    std::vector<Rot> rot(bdsqr_log_steps_cap(m));
+    bdsqr_gen(ctx, m, d.data(), e.data(), hdr.data(), rot.data(), &nb, &info);
+    bdsqr_apply_rows(ctx, m, Q.data(), m, 0, m, 0, hdr.data(), rot.data(), nb);
+    bdsqr_apply_rows(ctx, m, P.data(), m, 0, m, 1, hdr.data(), rot.data(), nb);
     sort_sv(ctx, m, d.data(), Q.data(), m, P.data(), m, s_out, reinterpret_cast<cd*>(L_out), m,
             reinterpret_cast<cd*>(R_out), m);
     return info;
@@ -47,13 +53,13 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
 
 // bidiagonalisation only: returns d, e and explicit Q, P (for stage debugging)
 int hs_bidiag(const double* A_in, int m, double* d, double* e, double* Q_out, double* P_out) {
-    std::vector<cd> A(m * m), tq(m), tp(m);
+    std::vector<cd> A(m * m), UR(m * m), tq(m), tp(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
     HostCtx ctx = make_ctx(arena, bidiag_scratch_bytes(m, 1, 1));
-    bidiag(ctx, m, A.data(), m, d, e, tq.data(), tp.data());
-    gen_q(ctx, m, A.data(), m, tq.data(), reinterpret_cast<cd*>(Q_out), m);
-    gen_p(ctx, m, A.data(), m, tp.data(), reinterpret_cast<cd*>(P_out), m);
+    bidiag(ctx, m, A.data(), m, d, e, tq.data(), tp.data(), UR.data(), m);
+    gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), reinterpret_cast<cd*>(Q_out), m, 0, m);
+    gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), reinterpret_cast<cd*>(P_out), m, 0, m);
     return 0;
 }
 
@@ -63,9 +69,9 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
     HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n) +
-                                      hqr_ms_scratch_bytes(KB_MS_NSMAX));
+                                      hqr_win_scratch_bytes(8, 60));
     gehd2(ctx, n, W.data(), n, th.data());
-    gen_qh(ctx, n, W.data(), n, th.data(), Qh.data(), n);
+    gen_unitary_cols<HostCtx, HS_MAXC>(ctx, n, n - 2, 1, W.data(), n, th.data(), Qh.data(), n, 0, n);
     hess_copy(ctx, n, W.data(), n, Hc.data(), n);
     // infinity norm of H (zhsein: hnorm = zlanhs('I'))
     double hnorm = 0.0;
@@ -76,7 +82,7 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     }
     int info = 0, weak = 0;
     cd* mu = reinterpret_cast<cd*>(mu_out);
-    hqr_eigvals_ms(ctx, n, Hc.data(), n, mu, &info, 16);   // the variant the k_hqr kernel runs
+    hqr_eigvals_ms(ctx, n, Hc.data(), n, mu, &info, 8, nullptr, 60);   // the variant the k_hqr kernel runs
     invit<HostCtx, 4096>(ctx, n, W.data(), n, mu, hnorm, X.data(), n, 1, &weak);
     // P = Qh * X
     cd* P = reinterpret_cast<cd*>(P_out);
@@ -91,17 +97,17 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
 
 
 // eigenvalues only, multishift variant; stats = {intervals, batches, single_sweeps}
-int hs_eigvals_ms(const double* W_in, int n, int nsmax, double* mu_out, long long* stats_out) {
+int hs_eigvals_ms(const double* W_in, int n, int nsmax, int win_w, double* mu_out, long long* stats_out) {
     std::vector<cd> W(n * n), Hc(n * n), Ht(n * n), th(n);
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_ms_scratch_bytes(nsmax));
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_win_scratch_bytes(nsmax > KB_MS_NSMAX ? KB_MS_NSMAX : nsmax, win_w > 0 ? win_w : 8));
     gehd2(ctx, n, W.data(), n, th.data());
     hess_copy(ctx, n, W.data(), n, Hc.data(), n);
     int info = 0;
     MsStats st = {0, 0, 0, 0};
-    hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st);
-    if (stats_out) { stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; }
+    hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st, win_w);
+    if (stats_out) { stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps; }
     return info;
 }
 
