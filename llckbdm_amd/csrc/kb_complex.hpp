@@ -17,7 +17,7 @@
 
 namespace kb {
 
-struct cd {
+struct alignas(16) cd {
     double x, y;
 };
 

@@ -63,14 +63,36 @@ KB_HD void hess_copy(const C& ctx, int n, const cd* W, int ld, cd* Hc, int ldc) 
 }
 
 // 2-element Householder (zlarfg with n = 2), scalar.
+// On the device the square root and the three divisions are replaced by one reciprocal
+// square root and one reciprocal (hardware seed + Newton steps): this routine sits on the
+// serial critical path of every bulge-chasing interval.
 KB_HD void larfg2(cd& alpha, cd& x, cd& tau) {
-    const double xn = cabs(x);
-    if (xn == 0.0 && alpha.y == 0.0) { tau = czero(); return; }
-    const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn * xn);
+    const double xn2 = x.x * x.x + x.y * x.y;
+    if (xn2 == 0.0 && alpha.y == 0.0) { tau = czero(); return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double t = fma(alpha.x, alpha.x, fma(alpha.y, alpha.y, xn2));
+    double rs = __builtin_amdgcn_rsq(t);
+    rs = rs * fma(-0.5 * t * rs, rs, 1.5);
+    rs = rs * fma(-0.5 * t * rs, rs, 1.5);
+    const double nrm = t * rs;
+    const double beta = (alpha.x >= 0.0) ? -nrm : nrm;
+    const double ib = (alpha.x >= 0.0) ? -rs : rs;                 // 1 / beta
+    tau = mk((beta - alpha.x) * ib, -alpha.y * ib);
+    // x / (alpha - beta) = x * conj(d) / |d|^2
+    const double dr = alpha.x - beta, di = alpha.y;
+    const double d2 = fma(dr, dr, di * di);
+    double r = __builtin_amdgcn_rcp(d2);
+    r = r * fma(-d2, r, 2.0);
+    r = r * fma(-d2, r, 2.0);
+    x = mk((x.x * dr + x.y * di) * r, (x.y * dr - x.x * di) * r);
+    alpha = mk(beta, 0.0);
+#else
+    const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn2);
     const double beta = (alpha.x >= 0.0) ? -nrm : nrm;
     tau = mk((beta - alpha.x) / beta, -alpha.y / beta);
     x = cdiv(x, mk(alpha.x - beta, alpha.y));
     alpha = mk(beta, 0.0);
+#endif
 }
 
 // Eigenvalues of the upper Hessenberg H (destroyed).  LAPACK zlahqr, eigenvalues only:

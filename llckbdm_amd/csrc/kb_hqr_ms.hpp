@@ -20,6 +20,7 @@ constexpr int KB_MS_MIN = 12;     // below this active size: single-shift sweeps
 constexpr int KB_MS_NSMAX = 32;   // compile-time cap on simultaneous shifts
 constexpr int KB_MS_BU = 4;       // bulges whose loads are batched together
 constexpr int KB_MS_CU = 2;       // row/column chunks per thread batched together
+constexpr int KB_MS_RG = 8;       // bulges replayed as independent chains in the strip update
 
 // The lanes of ONE wavefront presented as a tiny workgroup (for the small shift solver).
 template <class C>
@@ -47,6 +48,11 @@ struct WaveCtx {
     KB_HD int block_max(int v) const { c.wave_fence(); return c.wave_max(v); }
 };
 
+template <int N>
+struct KbInt {
+    static constexpr int value = N;
+};
+
 struct MsRefl {
     cd t1;
     cd v2;
@@ -57,9 +63,17 @@ struct MsRefl {
     int pad;
 };
 
-struct MsStats {          // optional instrumentation (host simulation only)
+struct MsStats {          // optional instrumentation (host simulation / KBDM_HQR_PROF=1)
     long long intervals, batches, single_sweeps, small_steps;
+    long long cyc_scan, cyc_shift, cyc_load, cyc_chase, cyc_store, cyc_strip, cyc_single, cyc_total;
+    long long cyc_tload, cyc_treplay, cyc_tstore, ntiles;
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KB_CLOCK() ((long long)clock64())
+#else
+#define KB_CLOCK() (0LL)
+#endif
 
 KB_HD int hqr_ms_scratch_bytes(int nsmax) {
     return (nsmax * nsmax + nsmax) * (int)sizeof(cd) + nsmax * (int)sizeof(MsRefl) + 64;
@@ -310,10 +324,16 @@ KB_HD void chase_global(const C& ctx, cd* H, int ld, int l, int i, int ns, const
 // from LDS tiles: each strip element is read and written once per window step, and the
 // replay keeps one operand in a register (bulge-major order: reflectors of different bulges
 // act on disjoint rows whenever their time order is swapped, so they commute).
-KB_HD int hqr_win_scratch_bytes(int nsmax, int W) {
-    // shift solver area + reflector table (hqr_ms_scratch_bytes), window image, second tile, log
+KB_HD int hqr_win_area_elems(int W, int ws) {
+    // one LDS image: the W x W window (pitch W+1) or a strip tile of W x wavesize (pitch ws+1)
+    const int pitch = (W > ws ? W : ws) + 1;
+    return W * pitch;
+}
+KB_HD int hqr_win_scratch_bytes(int nsmax, int W, int ws) {
+    // shift solver area + reflector table (hqr_ms_scratch_bytes), two images, log
     const int logcap = (W + 2) * nsmax;
-    return hqr_ms_scratch_bytes(nsmax) + 2 * W * (W + 1) * (int)sizeof(cd) + logcap * (int)sizeof(MsRefl) + 128;
+    return hqr_ms_scratch_bytes(nsmax) + 2 * hqr_win_area_elems(W, ws) * (int)sizeof(cd) +
+           logcap * (int)sizeof(MsRefl) + 128;
 }
 
 template <class C>
@@ -326,9 +346,11 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
     const int WP = W + 1;                                   // padded pitch of the LDS images
     // scratch carve (after the areas hqr_eigvals_ms already uses: S, sh, refl, sinfo)
     char* base = reinterpret_cast<char*>(refl + nsmax) + 64;   // past refl[nsmax] and the info word
+    const int TP = C::WS + 1;                               // pitch of a strip tile (one lane per column/row)
+    const int area = hqr_win_area_elems(W, C::WS);
     cd* Hw = reinterpret_cast<cd*>(base);
-    cd* Tile = Hw + (size_t)W * WP;
-    MsRefl* logv = reinterpret_cast<MsRefl*>(Tile + (size_t)W * WP);
+    cd* Tile = Hw + area;
+    MsRefl* logv = reinterpret_cast<MsRefl*>(Tile + area);
     const int T = (na - 1) + 3 * (ns - 1);
     int t0 = 0;
     while (t0 < T) {
@@ -342,7 +364,7 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
         if (we > i + 1) we = i + 1;
         // ---- how many intervals fit: lowest bulge must keep k+2 inside the window
         int t1 = t0;
-        for (; t1 < T; ++t1) {
+        for (; t1 < T && t1 - t0 < W; ++t1) {             // at most W intervals per step (log capacity)
             int blo = 0;
             if (t1 - (na - 2) > 0) blo = (t1 - (na - 2) + 2) / 3;
             const int kmax = l + t1 - 3 * blo;
@@ -362,12 +384,14 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
         // log, bulge-major: entry (b - bmin) * nint + (t - t0); k < 0 marks "not active"
         for (int idx = tid; idx < (bmax - bmin + 1) * nint; idx += nt) logv[idx].k = -1;
         // ---- (a) load the diagonal window
+        const long long c_a = KB_CLOCK();
         const int wlen = we - ws;
         for (int idx = tid; idx < wlen * wlen; idx += nt) {
             const int r = idx % wlen, c = idx / wlen;
             Hw[r + c * WP] = HH(ws + r, ws + c);
         }
         ctx.sync();
+        const long long c_b = KB_CLOCK();
         // ---- (b) chase inside the window, logging the reflectors
         for (int t = t0; t < t1; ++t) {
             int b_hi = t / 3;
@@ -426,61 +450,151 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
             ctx.sync();
         }
         // ---- (c) store the window back
+        const long long c_c = KB_CLOCK();
         for (int idx = tid; idx < wlen * wlen; idx += nt) {
             const int r = idx % wlen, c = idx / wlen;
             HH(ws + r, ws + c) = Hw[r + c * WP];
         }
         ctx.sync();
+        const long long c_d = KB_CLOCK();
         // Replay the log bulge-major.  Two LDS tiles (the window image is free now):
         // wavefronts 0 and 1.
+        // Two LDS tiles (the window image is free now).  With four wavefronts, two share a tile
+        // and split its bulges (and its rows for the copies); a bulge on one wavefront may
+        // follow a bulge of the other by two intervals on the same rows, hence one workgroup
+        // barrier per interval.  Every wavefront runs the same trip counts (barrier safety).
         const int ntb = (ctx.nwaves() >= 2) ? 2 : 1;
+        const int nhalf = (ctx.nwaves() >= 2 * ntb) ? 2 : 1;
+        const int slot = ctx.wave() % ntb, half = ctx.wave() / ntb;
+        const bool worker = ctx.wave() < ntb * nhalf;
         // ---- (d) right strip: rows ws..we-1, columns we..i ; lanes = columns
         // ---- (e) top strip:   rows l..ws-1,  columns ws..we-1 ; lanes = rows
         const int nright = (we <= i) ? i - we + 1 : 0;
         const int ntop = ws - l;
         const int tiles_r = (nright + C::WS - 1) / C::WS, tiles_t = (ntop + C::WS - 1) / C::WS;
-        if (ctx.wave() < ntb) {
-            cd* Tl = (ctx.wave() == 0) ? Hw : Tile;
-            const int lane = ctx.lane();
-            for (int tile = ctx.wave(); tile < tiles_r + tiles_t; tile += ntb) {
-                const bool right = tile < tiles_r;
-                const int q0 = right ? we + tile * C::WS : l + (tile - tiles_r) * C::WS;
-                const int q = q0 + lane;
-                const bool live = right ? (q <= i) : (q < ws);
-                // load: Tl[p * WP + lane] = element p of this lane's column (right) / row (top)
-                if (live)
-                    for (int p = 0; p < wlen; ++p) Tl[p * WP + lane] = right ? HH(ws + p, q) : HH(q, ws + p);
-                ctx.wave_fence();
-                if (live) {
-                    for (int b = 0; b <= bmax - bmin; ++b) {
-                        bool have = false;
-                        cd carry = czero();
-                        int pc = 0;
-                        for (int tt = 0; tt < nint; ++tt) {
-                            const MsRefl rf = logv[b * nint + tt];
-                            if (rf.k < 0) continue;
-                            const int p = rf.k - ws;
-                            if (!have) { carry = Tl[p * WP + lane]; have = true; }
-                            const cd bb = Tl[(p + 1) * WP + lane];
-                            cd sum, bnew;
-                            if (right) { sum = conj(rf.t1) * carry + conj(rf.t2) * bb; bnew = bb - sum * rf.v2; }
-                            else { sum = rf.t1 * carry + rf.t2 * bb; bnew = bb - sum * conj(rf.v2); }
-                            Tl[p * WP + lane] = carry - sum;
-                            carry = bnew;
-                            pc = p + 1;
+        const int ntiles = tiles_r + tiles_t;
+        cd* Tl = (slot == 0) ? Hw : Tile;
+        const int lane = ctx.lane();
+        const int ngrp = (bmax - bmin) / KB_MS_RG + 1;
+        constexpr int UH = KB_MS_RG / 2;                       // bulges per wavefront when a tile is shared
+        for (int round = 0; round * ntb < ntiles; ++round) {
+            const int tile = round * ntb + slot;
+            const bool right = tile < tiles_r;
+            const int q = (right ? we + tile * C::WS : l + (tile - tiles_r) * C::WS) + lane;
+            const bool live = worker && tile < ntiles && (right ? (q <= i) : (q < ws));
+            const double sg = right ? -1.0 : 1.0;                // right strip uses conj(t1), conj(t2), v2
+            const long long c_t0 = KB_CLOCK();
+            if (live) {
+                // this wavefront's share of the rows; eight global loads in flight per lane
+                int p = half;
+                for (; p + 7 * nhalf < wlen; p += 8 * nhalf) {
+                    cd v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = right ? HH(ws + p + u * nhalf, q) : HH(q, ws + p + u * nhalf);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) Tl[(p + u * nhalf) * TP + lane] = v[u];
+                }
+                for (; p < wlen; p += nhalf) Tl[p * TP + lane] = right ? HH(ws + p, q) : HH(q, ws + p);
+            }
+            ctx.sync();
+            const long long c_t1 = KB_CLOCK();
+            auto replay = [&](auto nu_tag) {
+                constexpr int NU = decltype(nu_tag)::value;      // bulges handled by this wavefront per group
+                for (int g = 0; g < ngrp; ++g) {
+                    const int g0 = g * KB_MS_RG;
+                    int tb[NU], te[NU], pp[NU];
+                    cd carry[NU];
+                    int tt_lo = nint, tt_hi = 0;
+                    // interval range of the whole group (uniform over the workgroup)
+                    for (int u = 0; u < KB_MS_RG; ++u) {
+                        const int bb_ = bmin + g0 + u;
+                        int b0_ = 3 * bb_ - t0;
+                        if (b0_ < 0) b0_ = 0;
+                        int e0_ = 3 * bb_ + (na - 2) - t0 + 1;
+                        if (e0_ > nint) e0_ = nint;
+                        if (g0 + u <= bmax - bmin && e0_ > b0_) {
+                            tt_lo = b0_ < tt_lo ? b0_ : tt_lo;
+                            tt_hi = e0_ > tt_hi ? e0_ : tt_hi;
                         }
-                        if (have) Tl[pc * WP + lane] = carry;
                     }
-                    for (int p = 0; p < wlen; ++p) {
-                        if (right) HH(ws + p, q) = Tl[p * WP + lane];
-                        else HH(q, ws + p) = Tl[p * WP + lane];
+                    // the bulges this wavefront replays: local u -> group index uo(u)
+                    const int u_base = (nhalf == 2) ? half * UH : 0;
+                    const int u_cnt = NU;
+    #pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int gu = u_base + u;
+                        const int bb_ = bmin + g0 + gu;
+                        int b0_ = 3 * bb_ - t0;
+                        if (b0_ < 0) b0_ = 0;
+                        int e0_ = 3 * bb_ + (na - 2) - t0 + 1;
+                        if (e0_ > nint) e0_ = nint;
+                        if (u >= u_cnt || g0 + gu > bmax - bmin) { b0_ = 0; e0_ = 0; }
+                        tb[u] = b0_; te[u] = e0_;
+                        pp[u] = (l + (t0 + b0_) - 3 * bb_) - ws;
+                        carry[u] = czero();
+                    }
+                    for (int tt = tt_lo; tt < tt_hi; ++tt) {
+                        if (live) {
+                            // LDS reads of the interval, then the arithmetic, then the writes
+                            cd nbv[NU], c1v[NU], c2v[NU], c3v[NU], outv[NU];
+#pragma unroll
+                            for (int u = 0; u < NU; ++u) {
+                                if (tt >= tb[u] && tt < te[u]) {
+                                    const int p = pp[u] + (tt - tb[u]);
+                                    const MsRefl* lg = logv + (g0 + u_base + u) * nint + tt;
+                                    if (tt == tb[u]) carry[u] = Tl[p * TP + lane];
+                                    nbv[u] = Tl[(p + 1) * TP + lane];
+                                    const cd t1 = lg->t1, t2 = lg->t2, v2 = lg->v2;
+                                    c1v[u] = mk(t1.x, sg * t1.y);
+                                    c2v[u] = mk(t2.x, sg * t2.y);
+                                    c3v[u] = mk(v2.x, -sg * v2.y);
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < NU; ++u) {
+                                if (tt >= tb[u] && tt < te[u]) {
+                                    const cd sum = c1v[u] * carry[u] + c2v[u] * nbv[u];
+                                    outv[u] = carry[u] - sum;
+                                    carry[u] = nbv[u] - sum * c3v[u];
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < NU; ++u) {
+                                if (tt >= tb[u] && tt < te[u]) {
+                                    const int p = pp[u] + (tt - tb[u]);
+                                    Tl[p * TP + lane] = outv[u];
+                                    if (tt == te[u] - 1) Tl[(p + 1) * TP + lane] = carry[u];
+                                }
+                            }
+                        }
+                        if (nhalf == 2) ctx.sync();
                     }
                 }
-                ctx.wave_fence();
+            };
+            if (nhalf == 2) replay(KbInt<UH>{});
+            else replay(KbInt<KB_MS_RG>{});
+            ctx.sync();
+            const long long c_t2 = KB_CLOCK();
+            if (live) {
+                for (int p = half; p < wlen; p += nhalf) {
+                    if (right) HH(ws + p, q) = Tl[p * TP + lane];
+                    else HH(q, ws + p) = Tl[p * TP + lane];
+                }
+            }
+            ctx.sync();
+            if (stats && tid == 0) {
+                const long long c_t3 = KB_CLOCK();
+                stats->cyc_tload += c_t1 - c_t0; stats->cyc_treplay += c_t2 - c_t1; stats->cyc_tstore += c_t3 - c_t2;
+                stats->ntiles++;
             }
         }
         ctx.sync();
-        if (stats && tid == 0) stats->small_steps++;
+        if (stats && tid == 0) {
+            const long long c_e = KB_CLOCK();
+            stats->small_steps++;
+            stats->cyc_load += c_b - c_a; stats->cyc_chase += c_c - c_b;
+            stats->cyc_store += c_d - c_c; stats->cyc_strip += c_e - c_d;
+        }
         t0 = t1;
     }
 #undef HW
@@ -525,10 +639,12 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
     const int itmax = 30 * (n > 10 ? n : 10);
     int kdefl = 0;
     int i = n - 1;
+    const long long c_total0 = KB_CLOCK();
     while (i >= 0) {
         int l = 0;
         int done = 0;   // 1: H(i,i) converged, 2: 2x2 block solved
         for (int its = 0; its <= itmax; ++its) {
+            const long long c_scan0 = KB_CLOCK();
             // ---- deflation scan: largest k in (l, i] with a negligible subdiagonal
             int kf = l;
             for (int k = l + 1 + tid; k <= i; k += nt) {
@@ -558,6 +674,7 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
             if (l > 0 && tid == 0) HH(l, l - 1) = czero();
             if (l >= i) { done = 1; break; }
             ctx.sync();
+            if (stats && tid == 0) stats->cyc_scan += KB_CLOCK() - c_scan0;
             const int na = i - l + 1;
             if (na == 2) {
                 if (tid == 0) {
@@ -570,9 +687,11 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
             }
             kdefl++;
             if (na < KB_MS_MIN || nsmax < 2) {
+                const long long c0 = KB_CLOCK();
                 single_shift_sweep(ctx, H, ld, l, i, kdefl);
-                if (stats && tid == 0) stats->single_sweeps++;
+                if (stats && tid == 0) { stats->single_sweeps++; stats->cyc_single += KB_CLOCK() - c0; }
             } else {
+                const long long c_sh0 = KB_CLOCK();
                 int ns = na / 3;
                 if (ns > nsmax) ns = nsmax;
                 if (ns < 2) ns = 2;
@@ -596,6 +715,7 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
                     }
                 }
                 ctx.sync();
+                if (stats && tid == 0) stats->cyc_shift += KB_CLOCK() - c_sh0;
                 // ---- pipelined chase of ns bulges, 3 rows apart
                 const int T = (na - 1) + 3 * (ns - 1);
                 if (win_w >= 3 * ns + 8)
@@ -632,6 +752,7 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
         ctx.sync();
     }
     if (tid == 0) *info = fail;
+    if (stats && tid == 0) stats->cyc_total += KB_CLOCK() - c_total0;
     ctx.sync();
 #undef HH
 }

@@ -54,7 +54,7 @@ struct kbdm_ctx {
     int nt_hqr = 256;
     int nt_invit = 1024;
     int ns_hqr = 8;       // simultaneous shifts (bulges) of the QR iteration
-    int win_hqr = 60;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
+    int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
     int split_gen = 4;    // workgroups per item and matrix in k_gen
     int split_invit = 4;  // workgroups per item in k_invit
     double ws_budget_gib = 96.0;
@@ -309,13 +309,30 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     }
     {
         int win = ctx->win_hqr;
-        int sm = KB_RED_BYTES + (win > 0 ? hqr_win_scratch_bytes(ctx->ns_hqr, win) : hqr_ms_scratch_bytes(ctx->ns_hqr));
+        int sm = KB_RED_BYTES + (win > 0 ? hqr_win_scratch_bytes(ctx->ns_hqr, win, 64) : hqr_ms_scratch_bytes(ctx->ns_hqr));
         if (sm > LDS_MAX - 64) {   // window does not fit LDS with this many shifts: unblocked chase
             win = 0;
             sm = KB_RED_BYTES + hqr_ms_scratch_bytes(ctx->ns_hqr);
         }
+        MsStats* prof = nullptr;
+        const bool do_prof = env_int("KBDM_HQR_PROF", 0) != 0;
+        if (do_prof) {
+            HIPCHK(hipMalloc(&prof, sizeof(MsStats) * pl->B));
+            HIPCHK(hipMemsetAsync(prof, 0, sizeof(MsStats) * pl->B, st));
+        }
         hipLaunchKernelGGL(k_hqr, dim3(ch.count), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win);
+                           pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof);
+        if (do_prof) {   // diagnostic build path only: synchronous dump of the largest item's counters
+            std::vector<MsStats> h(pl->B);
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpy(h.data(), prof, sizeof(MsStats) * pl->B, hipMemcpyDeviceToHost));
+            const MsStats& x = h[pl->perm[ch.first]];
+            fprintf(stderr, "[k_hqr prof] n=%d batches=%lld intervals=%lld winsteps=%lld singles=%lld | Mcycles: total=%.1f scan=%.1f shift=%.1f load=%.1f chase=%.1f store=%.1f strip=%.1f single=%.1f | wave0 tiles=%lld tload=%.1f treplay=%.1f tstore=%.1f\n",
+                    pl->items[pl->perm[ch.first]].l, x.batches, x.intervals, x.small_steps, x.single_sweeps, x.cyc_total / 1e6,
+                    x.cyc_scan / 1e6, x.cyc_shift / 1e6, x.cyc_load / 1e6, x.cyc_chase / 1e6, x.cyc_store / 1e6,
+                    x.cyc_strip / 1e6, x.cyc_single / 1e6, x.ntiles, x.cyc_tload / 1e6, x.cyc_treplay / 1e6, x.cyc_tstore / 1e6);
+            hipFree(prof);
+        }
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {

@@ -311,14 +311,14 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
 
 __global__ void __launch_bounds__(256) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                cd* arena, double* varena, cd* mu_out, int* status,
-                                               int smem_bytes, int nsmax, int win_w) {
+                                               int smem_bytes, int nsmax, int win_w, MsStats* prof) {
     const int item = perm[blockIdx.x];
     const KbItem it = items[item];
     const DevCtx ctx = make_ctx(smem_bytes);
     cd* Hc = arena + it.off[KB_BUF_H];
     cd* mu = mu_out + it.line_off;
     __shared__ int info;
-    hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, nullptr, win_w);
+    hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, prof ? prof + item : nullptr, win_w);
     if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
 }
 

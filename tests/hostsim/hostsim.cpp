@@ -69,7 +69,7 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
     HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n) +
-                                      hqr_win_scratch_bytes(8, 60));
+                                      hqr_win_scratch_bytes(8, 60, 1));
     gehd2(ctx, n, W.data(), n, th.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, n, n - 2, 1, W.data(), n, th.data(), Qh.data(), n, 0, n);
     hess_copy(ctx, n, W.data(), n, Hc.data(), n);
@@ -101,11 +101,12 @@ int hs_eigvals_ms(const double* W_in, int n, int nsmax, int win_w, double* mu_ou
     std::vector<cd> W(n * n), Hc(n * n), Ht(n * n), th(n);
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_win_scratch_bytes(nsmax > KB_MS_NSMAX ? KB_MS_NSMAX : nsmax, win_w > 0 ? win_w : 8));
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_win_scratch_bytes(nsmax > KB_MS_NSMAX ? KB_MS_NSMAX : nsmax, win_w > 0 ? win_w : 8, 1));
     gehd2(ctx, n, W.data(), n, th.data());
     hess_copy(ctx, n, W.data(), n, Hc.data(), n);
     int info = 0;
-    MsStats st = {0, 0, 0, 0};
+    MsStats st;
+    memset(&st, 0, sizeof(st));
     hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st, win_w);
     if (stats_out) { stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps; }
     return info;
