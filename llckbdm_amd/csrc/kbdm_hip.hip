@@ -49,6 +49,8 @@ const char* kStageNames[KBDM_NSTAGES] = {"k_hankel",  "k_svd_fac", "k_gen(Q,P)",
 struct kbdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: work that is independent of the main chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nt_fac = 1024;    // threads per workgroup: bidiagonalisation / Hessenberg kernels
     int nt_bdsqr = 1024;
     int nt_hqr = 256;
@@ -231,16 +233,16 @@ struct StageTimer {
 int smem_fac(int n, int nt) { return KB_RED_BYTES + bidiag_scratch_bytes(n, nt / 64, 64); }
 
 // k_gen with the smallest register-chunk count that covers the largest item of the launch
-int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat) {
+int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream_t gst) {
     kbdm_ctx* ctx = pl->ctx;
     const int* perm = pl->d_perm + ch.first;
     dim3 grid(ctx->split_gen, ch.count, nmat), block(256);
     const int chunks = (nmax + 63) / 64;
-    if (chunks <= 2) hipLaunchKernelGGL(k_gen<2>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 4) hipLaunchKernelGGL(k_gen<4>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 8) hipLaunchKernelGGL(k_gen<8>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 16) hipLaunchKernelGGL(k_gen<16>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 32) hipLaunchKernelGGL(k_gen<32>, grid, block, 0, ctx->stream, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    if (chunks <= 2) hipLaunchKernelGGL(k_gen<2>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 4) hipLaunchKernelGGL(k_gen<4>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 8) hipLaunchKernelGGL(k_gen<8>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 16) hipLaunchKernelGGL(k_gen<16>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+    else if (chunks <= 32) hipLaunchKernelGGL(k_gen<32>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
     else return fail(KBDM_E_NOMEM, "m larger than 2048 is not supported by k_gen");
     return KBDM_OK;
 }
@@ -256,29 +258,50 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                            pl->d_varena, sm);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
-    {
-        int r = launch_gen(pl, ch, ch.mmax, 0, 2);
-        if (r) return r;
-        if (tm) { r = tm->mark(); if (r) return r; }
-    }
+    // The scalar QR iteration needs only (d, e): it runs on the side stream while the main
+    // stream accumulates Q and P.  (Its stage timer therefore shows ~0; k_gen(Q,P)'s slot spans
+    // max(k_gen, k_bdsqr_gen).)
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     {
         const int sm = KB_RED_BYTES + bdsqr_gen_scratch_bytes(ch.mmax);
         if (sm > LDS_MAX - 64) return fail(KBDM_E_NOMEM, "m too large for the bidiagonal QR scratch");
-        hipLaunchKernelGGL(k_bdsqr_gen, dim3(ch.count), dim3(64), sm, st, pl->d_items, perm, pl->d_varena, pl->d_hdr,
-                           pl->d_rot, pl->d_iwork, sm);
-        if (tm) { int r = tm->mark(); if (r) return r; }
+        hipLaunchKernelGGL(k_bdsqr_gen, dim3(ch.count), dim3(64), sm, ctx->stream2, pl->d_items, perm, pl->d_varena,
+                           pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     }
     {
-        // rows per wavefront: as many as fit LDS, at most 32 (two lanes per row: re / im)
-        int R = (LDS_MAX - 64 - KB_RED_BYTES) / ((ch.mmax + 1) * (int)sizeof(cd));
-        if (R < 1) return fail(KBDM_E_NOMEM, "m too large for the rotation replay");
-        if (R > 32) R = 32;
-        const int sm = KB_RED_BYTES + R * (ch.mmax + 1) * (int)sizeof(cd);
-        // smaller items get 32 rows per group out of the same LDS budget; grid.x covers the worst case
-        const int rmin = std::min(32, (sm - KB_RED_BYTES) / ((ch.mmax + 1) * (int)sizeof(cd)));
-        const int groups = (ch.mmax + rmin - 1) / rmin;
-        hipLaunchKernelGGL(k_bdsqr_apply, dim3(groups, ch.count, 2), dim3(64), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
+        int r = launch_gen(pl, ch, ch.mmax, 0, 2, st);
+        if (r) return r;
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        if (tm) { r = tm->mark(); if (r) return r; }
+        if (tm) { r = tm->mark(); if (r) return r; }      // k_bdsqr_gen slot (overlapped)
+    }
+    {
+        // Rotation replay, launched per size bucket: rows per wavefront = as many as fit the LDS
+        // granted to the bucket (at most 32: two lanes per row), so that small members do not
+        // inherit the LDS footprint - and the one-workgroup-per-CU occupancy - of the largest.
+        int pos = 0;
+        while (pos < ch.count) {
+            const int mhi = pl->items[pl->perm[ch.first + pos]].m;
+            const int rotb = 0;
+            int R = (LDS_MAX - 64 - KB_RED_BYTES - rotb) / ((mhi + 1) * (int)sizeof(cd));
+            if (R < 1) return fail(KBDM_E_NOMEM, "m too large for the rotation replay");
+            if (R > 32) R = 32;
+            const int sm = KB_RED_BYTES + rotb + R * (mhi + 1) * (int)sizeof(cd);
+            const int mlo = (R == 32) ? std::max(1, mhi - 48) : mhi - 16;     // bucket: members down to mlo
+            int end = pos, groups = 1;
+            while (end < ch.count && pl->items[pl->perm[ch.first + end]].m >= mlo) {
+                const int mi = pl->items[pl->perm[ch.first + end]].m;
+                int Ri = (sm - KB_RED_BYTES - rotb) / ((mi + 1) * (int)sizeof(cd));
+                if (Ri > 32) Ri = 32;
+                groups = std::max(groups, (mi + Ri - 1) / Ri);
+                ++end;
+            }
+            hipLaunchKernelGGL(k_bdsqr_apply, dim3(groups, end - pos, 2), dim3(64), sm, st, pl->d_items, perm + pos,
+                               pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
+            pos = end;
+        }
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
@@ -302,10 +325,14 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                            pl->d_varena, sm);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
+    // Qh is first needed by k_gemm<3>: accumulate it on the side stream while the QR iteration runs.
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     {
-        int r = launch_gen(pl, ch, ch.lmax, 1, 1);
+        int r = launch_gen(pl, ch, ch.lmax, 1, 1, ctx->stream2);
         if (r) return r;
-        if (tm) { r = tm->mark(); if (r) return r; }
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        if (tm) { r = tm->mark(); if (r) return r; }      // k_gen(Qh) slot (overlapped with k_hqr)
     }
     {
         int win = ctx->win_hqr;
@@ -342,6 +369,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         const int sm = KB_RED_BYTES + nw * per;
         hipLaunchKernelGGL(k_invit, dim3(ch.count, ctx->split_invit), dim3(ctx->nt_invit), sm, st, pl->d_items, perm,
                            pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm);
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));   // Qh ready before k_gemm<3>
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     HIPCHK(hipGetLastError());
@@ -383,6 +411,9 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     kbdm_ctx* c = new kbdm_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->nt_fac = env_int("KBDM_NT_FAC", c->nt_fac);
     c->nt_bdsqr = env_int("KBDM_NT_BDSQR", c->nt_bdsqr);
     c->nt_hqr = env_int("KBDM_NT_HQR", c->nt_hqr);
@@ -404,6 +435,9 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
 int kbdm_ctx_destroy(kbdm_ctx* ctx) {
     if (!ctx) return KBDM_OK;
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     delete ctx;
     return KBDM_OK;
 }
