@@ -58,7 +58,7 @@ struct kbdm_ctx {
     int ns_hqr = 8;       // simultaneous shifts (bulges) of the QR iteration
     int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
     int split_gen = 4;    // workgroups per item and matrix in k_gen
-    int split_invit = 4;  // workgroups per item in k_invit
+    int split_invit = 8;  // workgroups per item in k_invit
     double ws_budget_gib = 96.0;
 };
 
@@ -270,38 +270,50 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                            pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     }
+    // In-kernel hand-off (DONE flag per item) lets the replay of small members start while the
+    // generators of large members are still running.  Only when every generator wavefront is
+    // certainly resident before the replay starts (they were launched a whole kernel earlier and
+    // need one wavefront each); otherwise a stream dependency.
+    const bool flag_mode = ch.count <= 2048 && env_int("KBDM_BDSQR_FLAG", 1) != 0;
     {
         int r = launch_gen(pl, ch, ch.mmax, 0, 2, st);
         if (r) return r;
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        if (!flag_mode) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         if (tm) { r = tm->mark(); if (r) return r; }
         if (tm) { r = tm->mark(); if (r) return r; }      // k_bdsqr_gen slot (overlapped)
     }
     {
-        // Rotation replay, launched per size bucket: rows per wavefront = as many as fit the LDS
-        // granted to the bucket (at most 32: two lanes per row), so that small members do not
-        // inherit the LDS footprint - and the one-workgroup-per-CU occupancy - of the largest.
+        // Rotation replay, launched per size bucket, SMALLEST members first (their logs are
+        // complete first): rows per wavefront = as many as fit the LDS granted to the bucket
+        // (at most 32: two lanes per row), so that small members do not inherit the LDS
+        // footprint - and the one-workgroup-per-CU occupancy - of the largest.
+        struct Bucket { int pos, cnt, groups, sm; };
+        std::vector<Bucket> buckets;
         int pos = 0;
         while (pos < ch.count) {
             const int mhi = pl->items[pl->perm[ch.first + pos]].m;
-            const int rotb = 0;
-            int R = (LDS_MAX - 64 - KB_RED_BYTES - rotb) / ((mhi + 1) * (int)sizeof(cd));
+            int R = (LDS_MAX - 64 - KB_RED_BYTES) / ((mhi + 1) * (int)sizeof(cd));
             if (R < 1) return fail(KBDM_E_NOMEM, "m too large for the rotation replay");
             if (R > 32) R = 32;
-            const int sm = KB_RED_BYTES + rotb + R * (mhi + 1) * (int)sizeof(cd);
+            const int sm = KB_RED_BYTES + R * (mhi + 1) * (int)sizeof(cd);
             const int mlo = (R == 32) ? std::max(1, mhi - 48) : mhi - 16;     // bucket: members down to mlo
             int end = pos, groups = 1;
             while (end < ch.count && pl->items[pl->perm[ch.first + end]].m >= mlo) {
                 const int mi = pl->items[pl->perm[ch.first + end]].m;
-                int Ri = (sm - KB_RED_BYTES - rotb) / ((mi + 1) * (int)sizeof(cd));
+                int Ri = (sm - KB_RED_BYTES) / ((mi + 1) * (int)sizeof(cd));
                 if (Ri > 32) Ri = 32;
                 groups = std::max(groups, (mi + Ri - 1) / Ri);
                 ++end;
             }
-            hipLaunchKernelGGL(k_bdsqr_apply, dim3(groups, end - pos, 2), dim3(64), sm, st, pl->d_items, perm + pos,
-                               pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
+            buckets.push_back(Bucket{pos, end - pos, groups, sm});
             pos = end;
         }
+        for (int b = (int)buckets.size() - 1; b >= 0; --b) {
+            const Bucket& bk = buckets[b];
+            hipLaunchKernelGGL(k_bdsqr_apply, dim3(bk.groups, bk.cnt, 2), dim3(64), bk.sm, st, pl->d_items,
+                               perm + bk.pos, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, bk.sm, flag_mode ? 1 : 0);
+        }
+        if (flag_mode) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
@@ -492,6 +504,7 @@ int kbdm_plan_execute(kbdm_plan* pl) {
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemsetAsync(pl->d_status, 0, sizeof(int) * pl->B, st));
+    HIPCHK(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * 4 * pl->B, st));
     for (auto& ch : pl->chunks) {
         StageTimer tm{pl, &ch};
         int r = tm.init();
@@ -664,6 +677,7 @@ int kbdm_svd_batch(kbdm_ctx* ctx, const double* A, int B, const int32_t* m, doub
         if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
         hipMemcpy(d_dense, A, sizeof(cd) * tot, hipMemcpyHostToDevice);
         hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
+        hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * 4 * B, st);
         for (auto& ch : pl->chunks) {
             // stage plans are built in one chunk by construction of the tests; handle generally
             hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_A, 0);

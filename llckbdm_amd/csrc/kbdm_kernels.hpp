@@ -124,7 +124,9 @@ __global__ void __launch_bounds__(256) k_gen(const KbItem* __restrict__ items, c
 }
 
 // Bidiagonal QR iteration, part 1: one wavefront per item runs the scalar recurrence on
-// (d, e) in LDS and logs every plane rotation (iwork[4*item] = batches, [4*item+1] = info).
+// (d, e) in LDS and logs every plane rotation.  iwork[4*item + {0,1,3}] = batches, info, DONE.
+// The DONE word is published with an agent-scope release so that the replay kernel, which may
+// already be running on the main stream, can start on this item the moment its log is complete.
 __global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                    double* varena, RotBatch* hdr_all, Rot* rot_all, int* iwork,
                                                    int smem_bytes) {
@@ -134,13 +136,23 @@ __global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ ite
     double* dv = varena + it.voff;
     bdsqr_gen(ctx, it.m, dv + KB_V_D * it.vstride, dv + KB_V_E * it.vstride, hdr_all + it.hdr_off,
               rot_all + it.rot_off, &iwork[4 * item], &iwork[4 * item + 1]);
+    // publish: every lane's stores drained, then release, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&iwork[4 * item + 3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Part 2: the logged rotations are applied to the rows of Q (blockIdx.z = 0) and P (= 1).
-// One wavefront owns a group of rows, staged in LDS for the whole replay.
+// One wavefront owns a group of rows, staged in LDS for the whole replay.  If `wait_flag`, the
+// kernel was launched without a stream dependency on k_bdsqr_gen and waits for the item's DONE
+// word itself (relaxed poll, one agent-scope acquire).
 __global__ void __launch_bounds__(64) k_bdsqr_apply(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                      cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
-                                                     const int* iwork, int smem_bytes) {
+                                                     int* iwork, int smem_bytes, int wait_flag) {
     const int item = perm[blockIdx.y];
     const KbItem it = items[item];
     const DevCtx ctx = make_ctx(smem_bytes);
@@ -150,9 +162,26 @@ __global__ void __launch_bounds__(64) k_bdsqr_apply(const KbItem* __restrict__ i
     const int row0 = blockIdx.x * R;
     if (row0 >= m) return;
     const int nrows = (row0 + R <= m) ? R : m - row0;
+    if (wait_flag) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&iwork[4 * item + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+                   spins < (1u << 26)) {
+                __builtin_amdgcn_s_sleep(32);
+                ++spins;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    // the log pointers are laundered so that no load of the log can be scheduled above the wait
+    const RotBatch* hdr = hdr_all + it.hdr_off;
+    const Rot* rot = rot_all + it.rot_off;
+    asm volatile("" : "+s"(hdr), "+s"(rot)::"memory");
+    const int nb = __hip_atomic_load(&iwork[4 * item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     cd* X = arena + it.off[blockIdx.z == 0 ? KB_BUF_Q : KB_BUF_P];
-    bdsqr_apply_rows(ctx, m, X, m, row0, nrows, (int)blockIdx.z, hdr_all + it.hdr_off, rot_all + it.rot_off,
-                     iwork[4 * item]);
+    bdsqr_apply_rows(ctx, m, X, m, row0, nrows, (int)blockIdx.z, hdr, rot, nb);
 }
 
 // Part 3: sign fix, descending sort, permuted copy into L (A buffer) and R, Dsqi, outputs.

@@ -196,3 +196,76 @@ def test_pseudo_noise_ensemble_properties(eng):
     rev, _, _ = sample_kbdm_signals(sigs[::-1], DWELL, list(range(S)), [256] * S, engine=eng)
     for a, b in zip(lls, rev[::-1]):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- BASELINE.json configs 3-5 (shapes)
+def _c4_signal(N=4096):
+    """C4 input: 16 CSV peaks + 16 seeded extra peaks, sigma = 1e-3."""
+    rng = np.random.default_rng(1)
+    extra = np.column_stack([rng.uniform(0.01, 1, 16), rng.uniform(0.005, 0.2, 16), rng.uniform(50, 950, 16),
+                             np.zeros(16)])
+    params = np.vstack([O.brain_sim_params_sorted(), extra])
+    t = np.arange(N) * DWELL
+    return O.make_noisy(O.multi_fid(t, params), 1e-3, 4), params
+
+
+def test_config3_shape_m512_pseudo_noise(eng):
+    """C3 at reduced count: fixed m = 512 (the largest m of the N=2048 configs), sigma = 1e-6 draws."""
+    base = O.brain_sim_signal(2048)
+    sigs = np.stack([O.make_noisy(base, 1e-6, 2000 + k) for k in range(4)])
+    res = eng.solve(sigs, [0, 1, 2, 3], [512] * 4, None, p=1, q=0.0, dwell=DWELL)
+    assert not res.status.any()
+    want, info = O.kbdm(sigs[2], DWELL, m=512, normalizer="gemm")
+    got = res.line_list(2)
+    assert np.abs(res.singular_values(2) - info.singular_values).max() < 1e-14 * 512 * info.singular_values[0]
+    truth = O.brain_sim_params_sorted()
+    k, w = canonical(got[keep_mask(got)]), canonical(O.filter_samples(want))
+    assert_lines_close(genuine_rows(k, truth), genuine_rows(w, truth), rel=1e-8, phase_abs=1e-8, what="C3 genuine")
+
+
+def test_config4_shape_N4096_up_to_m1200(eng):
+    """C4 shape: N = 4096, 32 peaks, ragged m up to the configuration's maximum 1200."""
+    sig, params = _c4_signal()
+    ms = [200, 611, 1200]
+    res = eng.solve(sig.reshape(1, -1), [0, 0, 0], ms, None, p=1, q=0.0, dwell=DWELL)
+    assert not res.status.any()
+    for i, m in enumerate(ms):
+        got = res.line_list(i)
+        assert got.shape == (m, 4) and np.isfinite(got[keep_mask(got)]).all()
+        sv = res.singular_values(i)
+        assert np.all(np.diff(sv) <= 0) and sv[-1] >= 0
+        # size-independent property: sum s_i^2 = ||U^0||_F^2 (Hankel: sample c_k appears
+        # min(k+1, 2m-1-k) times)
+        cnt = np.minimum(np.arange(2 * m - 1) + 1, 2 * m - 1 - np.arange(2 * m - 1))
+        fro2 = float(np.sum(cnt * np.abs(sig[:2 * m - 1]) ** 2))
+        assert abs(np.sum(sv ** 2) - fro2) < 1e-12 * fro2
+    sv1200 = np.linalg.svd(O.compute_U_matrices(sig, 1200, 1)[0], compute_uv=False)
+    assert np.abs(res.singular_values(2) - sv1200).max() < 1e-14 * 1200 * sv1200[0]
+    want, info = O.kbdm(sig, DWELL, m=611, normalizer="gemm")
+    assert np.abs(res.singular_values(1) - info.singular_values).max() < 1e-14 * 611 * info.singular_values[0]
+    k, w = canonical(res.line_list(1)[keep_mask(res.line_list(1))]), canonical(O.filter_samples(want))
+    assert len(k) == len(w)
+    assert_lines_close(k, w, rel=1e-7, phase_abs=1e-7, what="C4 m=611")
+
+
+def test_config5_shape_multi_voxel_grid(eng):
+    """C5 shape at reduced size: several signals (amplitude-scaled peaks) x an m-ensemble each."""
+    truth = O.brain_sim_params_sorted()
+    t = np.linspace(0, DWELL * 2048, 2048, endpoint=False)
+    sigs = []
+    for v in range(3):
+        p = truth.copy()
+        p[:, 0] *= np.random.default_rng(100 + v).uniform(0.5, 1.5, len(p))
+        sigs.append(O.make_noisy(O.multi_fid(t, p), 1e-3, 50 + v))
+    sigs = np.stack(sigs)
+    ms = list(range(128, 136))
+    sig_idx = np.repeat(np.arange(3), len(ms))
+    m_all = ms * 3
+    res = eng.solve(sigs, sig_idx, m_all, None, p=1, q=0.0, dwell=DWELL)
+    assert not res.status.any()
+    for i in (0, 11, 23):
+        want, _ = O.kbdm(sigs[sig_idx[i]], DWELL, m=m_all[i], normalizer="gemm")
+        got = res.line_list(i)
+        k, w = canonical(got[keep_mask(got)]), canonical(O.filter_samples(want))
+        assert len(k) == len(w)
+        assert_lines_close(k, w, rel=1e-8, phase_abs=1e-8, what=f"C5 item {i}")
