@@ -464,7 +464,8 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
         // follow a bulge of the other by two intervals on the same rows, hence one workgroup
         // barrier per interval.  Every wavefront runs the same trip counts (barrier safety).
         const int ntb = (ctx.nwaves() >= 2) ? 2 : 1;
-        const int nhalf = (ctx.nwaves() >= 2 * ntb) ? 2 : 1;
+        // wavefronts per tile: 1, 2, 4 or 8 (each takes KB_MS_RG / nhalf bulges of every group)
+        const int nhalf = (ctx.nwaves() >= 8 * ntb) ? 8 : (ctx.nwaves() >= 4 * ntb) ? 4 : ((ctx.nwaves() >= 2 * ntb) ? 2 : 1);
         const int slot = ctx.wave() % ntb, half = ctx.wave() / ntb;
         const bool worker = ctx.wave() < ntb * nhalf;
         // ---- (d) right strip: rows ws..we-1, columns we..i ; lanes = columns
@@ -476,7 +477,6 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
         cd* Tl = (slot == 0) ? Hw : Tile;
         const int lane = ctx.lane();
         const int ngrp = (bmax - bmin) / KB_MS_RG + 1;
-        constexpr int UH = KB_MS_RG / 2;                       // bulges per wavefront when a tile is shared
         for (int round = 0; round * ntb < ntiles; ++round) {
             const int tile = round * ntb + slot;
             const bool right = tile < tiles_r;
@@ -518,7 +518,7 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
                         }
                     }
                     // the bulges this wavefront replays: local u -> group index uo(u)
-                    const int u_base = (nhalf == 2) ? half * UH : 0;
+                    const int u_base = half * NU;
                     const int u_cnt = NU;
     #pragma unroll
                     for (int u = 0; u < NU; ++u) {
@@ -567,11 +567,13 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
                                 }
                             }
                         }
-                        if (nhalf == 2) ctx.sync();
+                        if (nhalf > 1) ctx.sync();
                     }
                 }
             };
-            if (nhalf == 2) replay(KbInt<UH>{});
+            if (nhalf == 8) replay(KbInt<KB_MS_RG / 8>{});
+            else if (nhalf == 4) replay(KbInt<KB_MS_RG / 4>{});
+            else if (nhalf == 2) replay(KbInt<KB_MS_RG / 2>{});
             else replay(KbInt<KB_MS_RG>{});
             ctx.sync();
             const long long c_t2 = KB_CLOCK();

@@ -53,7 +53,7 @@ struct kbdm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nt_fac = 1024;    // threads per workgroup: bidiagonalisation / Hessenberg kernels
     int nt_bdsqr = 1024;
-    int nt_hqr = 256;
+    int nt_hqr = 512;
     int nt_invit = 1024;
     int ns_hqr = 8;       // simultaneous shifts (bulges) of the QR iteration
     int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
@@ -436,7 +436,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     if (c->win_hqr > 0 && c->win_hqr < 3 * c->ns_hqr + 8) c->win_hqr = 3 * c->ns_hqr + 8;
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
-    if (c->nt_hqr > 256) c->nt_hqr = 256;   // k_hqr is compiled for <= 256 threads (register budget)
+    if (c->nt_hqr > 1024) c->nt_hqr = 1024;
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
     int r = set_lds_attr();
     if (r) { delete c; return r; }
