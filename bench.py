@@ -181,8 +181,15 @@ def main():
                 fl[k] = fl.get(k, 0.0) + v
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/), if any
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_final_pmc_traffic.json")))["kernels"]
+            traffic = pmc.get(dom, pmc.get(dom.split("(")[0], {})).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                     "avg_ms": stage_ms[dom], "algorithmic_flops_per_launch": fl[dom]}
         total_fl = sum(fl.values())
         out = {
