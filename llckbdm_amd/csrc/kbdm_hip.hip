@@ -105,6 +105,7 @@ size_t item_arena_elems(int m, int l) {
 
 int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svd_fac), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_gen), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_apply), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_sort), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -252,10 +253,22 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     hipStream_t st = ctx->stream;
     const int* perm = pl->d_perm + ch.first;
     {
+        // blocked part: panels + MFMA trailing updates (all inside the "k_svd_fac" stage timer)
+        const int npan = (env_int("KBDM_BLOCKED", 1) != 0) ? bidiag_num_panels(ch.mmax) : 0;
+        const int smp = KB_RED_BYTES + bidiag_panel_scratch_bytes(ch.mmax, ctx->nt_fac / 64, 64);
+        if (npan > 0 && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
+        for (int pnl = 0; pnl < npan; ++pnl) {
+            hipLaunchKernelGGL(k_bidiag_panel, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
+                               pl->d_arena, pl->d_varena, pnl, smp);
+            const int nn = ch.mmax - (pnl + 1) * KB_NB;
+            const int tiles = (nn + 63) / 64;
+            hipLaunchKernelGGL(k_trail_update, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
+                               pl->d_arena, pnl);
+        }
         const int sm = smem_fac(ch.mmax, ctx->nt_fac);
         if (sm > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the bidiagonalisation scratch");
         hipLaunchKernelGGL(k_svd_fac, dim3(ch.count), dim3(ctx->nt_fac), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, sm);
+                           pl->d_varena, sm, npan > 0 ? 1 : 0);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     // The scalar QR iteration needs only (d, e): it runs on the side stream while the main

@@ -4,7 +4,8 @@
 //
 // Pipeline (reference kbdm.py:64-92 per member; sampling.py:52-70 over members):
 //   k_hankel   U^{p-1} from the shared signal                      (kbdm.py:95-130)
-//   k_svd_fac  Householder bidiagonalisation                       (kbdm.py:166)
+//   k_bidiag_panel / k_trail_update / k_svd_fac   blocked Householder bidiagonalisation: panels of
+//              32 reflector pairs, FP64-MFMA rank-64 trailing update, unblocked tail   (kbdm.py:166)
 //   k_gen      explicit Q, P (and later Qh), columns in registers  (kbdm.py:166,192)
 //   k_bdsqr_gen / _apply / _sort   bidiagonal QR: logged rotations, LDS-resident row replay,
 //              sort -> L, s, R                                      (kbdm.py:166)
@@ -72,10 +73,108 @@ __global__ void __launch_bounds__(256) k_hankel(const KbItem* __restrict__ items
 }
 
 // ------------------------------------------------------------------------------------
-// One workgroup per item: Householder bidiagonalisation (left vectors stay in A, right
-// vectors go to the R buffer, which is free until the sort).
+// Householder bidiagonalisation, blocked: for panel p = 0, 1, ... (host loop)
+//   k_bidiag_panel  one workgroup per item: NB reflector pairs, X/Y panels (Q and P buffers are
+//                   free at this point), two matrix-vector products with the trailing matrix per column
+//   k_trail_update  all CUs: A0[NB:, NB:] -= [V | X] [Y | U]^H  with FP64 MFMA 16x16x4 tiles
+// then k_svd_fac finishes the last (< NB + NX) columns unblocked.
+// Left vectors stay in A, right vectors go to the R buffer (free until the sort).
+__global__ void __launch_bounds__(1024) k_bidiag_panel(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                        cd* arena, double* varena, int panel, int smem_bytes) {
+    const KbItem it = items[perm[blockIdx.x]];
+    const int m = it.m;
+    if (panel >= bidiag_num_panels(m)) return;
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const int p0 = panel * KB_NB;
+    cd* A = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;
+    cd* UR = arena + it.off[KB_BUF_R] + p0 + (size_t)p0 * m;
+    cd* X = arena + it.off[KB_BUF_Q];
+    cd* Y = arena + it.off[KB_BUF_P];
+    double* dv = varena + it.voff;
+    double* d = dv + KB_V_D * it.vstride + p0;
+    double* e = dv + KB_V_E * it.vstride + p0;
+    cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride) + p0;
+    cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride) + p0;
+    bidiag_panel(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
+}
+
+// Trailing update of one panel:  C[r, c] -= sum_k Aop[r, k] conj(Bop[c, k]),  r, c in [NB, n),
+// Aop = [V | X], Bop = [Y | U], K = 2 NB.  One workgroup = 64 x 64 block of C, each of its four
+// wavefronts a 32 x 32 sub-block as 2 x 2 v_mfma_f64_16x16x4_f64 tiles (real and imaginary
+// accumulators).  The MFMA computes D'[c][r] (output column on the MFMA row index) so that the
+// 16 lanes of a quarter-wave hold 16 consecutive ROWS of C: coalesced 256-byte read-modify-write.
+//   f64 MFMA operand maps (cdna_hip_programming.md 3): A: lane l -> A[l & 15][l >> 4],
+//   B: lane l -> B[l >> 4][l & 15],  C/D: col = l & 15, row = (l >> 4) + 4 * reg.
+typedef double kb_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_trail_update(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                       cd* arena, int panel) {
+    const KbItem it = items[perm[blockIdx.z]];
+    const int m = it.m;
+    if (panel >= bidiag_num_panels(m)) return;
+    const int p0 = panel * KB_NB;
+    const int n = m - p0;                        // trailing block size at panel start
+    const int nn = n - KB_NB;                    // updated block is nn x nn at local offset NB
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * 64 + (wave & 1) * 32;   // local to the updated block
+    const int c0 = blockIdx.y * 64 + (wave >> 1) * 32;
+    if (blockIdx.x * 64 >= nn || blockIdx.y * 64 >= nn) return;
+    const cd* A = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;    // V in columns 0..NB-1
+    const cd* UR = arena + it.off[KB_BUF_R] + p0 + (size_t)p0 * m;   // U
+    const cd* X = arena + it.off[KB_BUF_Q];
+    const cd* Y = arena + it.off[KB_BUF_P];
+    cd* C = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;
+    const int li = lane & 15, lk = lane >> 4;
+    kb_d4 acc_re[2][2], acc_im[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
+    for (int k0 = 0; k0 < 2 * KB_NB; k0 += 4) {
+        const int k = k0 + lk;
+        const bool second = k >= KB_NB;              // uniform per k0 (NB is a multiple of 4)
+        const int kk = second ? k - KB_NB : k;
+        cd av[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int r = KB_NB + r0 + a * 16 + li;  // row of C (local to the trailing block)
+            const int c = KB_NB + c0 + a * 16 + li;  // column of C
+            av[a] = (r < n) ? (second ? X[r + (size_t)kk * m] : A[r + (size_t)kk * m]) : czero();
+            bv[a] = (c < n) ? (second ? UR[c + (size_t)kk * m] : Y[c + (size_t)kk * m]) : czero();
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                // D'[c][r] += Bop(c,k) (MFMA A operand) * Aop(r,k) (MFMA B operand), complex with conj(Bop)
+                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].x, acc_re[cb][rb], 0, 0, 0);
+                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].y, av[rb].y, acc_re[cb][rb], 0, 0, 0);
+                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].y, acc_im[cb][rb], 0, 0, 0);
+                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bv[cb].y, av[rb].x, acc_im[cb][rb], 0, 0, 0);
+            }
+    }
+    // D' element (MFMA row = C column offset, MFMA col = C row offset): col = li, row = lk + 4*reg
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = KB_NB + r0 + rb * 16 + li;
+                const int c = KB_NB + c0 + cb * 16 + lk + 4 * g;
+                if (r < n && c < n) {
+                    cd* pc = &C[r + (size_t)c * m];
+                    cd v = *pc;
+                    v.x -= acc_re[cb][rb][g];
+                    v.y -= acc_im[cb][rb][g];
+                    *pc = v;
+                }
+            }
+}
+
+// One workgroup per item: the remaining columns, unblocked.
 __global__ void __launch_bounds__(1024) k_svd_fac(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                   cd* arena, double* varena, int smem_bytes) {
+                                                   cd* arena, double* varena, int smem_bytes, int blocked) {
     const KbItem it = items[perm[blockIdx.x]];
     const DevCtx ctx = make_ctx(smem_bytes);
     const int m = it.m;
@@ -86,7 +185,7 @@ __global__ void __launch_bounds__(1024) k_svd_fac(const KbItem* __restrict__ ite
     double* e = dv + KB_V_E * it.vstride;
     cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);
     cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride);
-    bidiag(ctx, m, A, m, d, e, tauq, taup, UR, m);
+    bidiag(ctx, m, A, m, d, e, tauq, taup, UR, m, blocked ? bidiag_num_panels(m) * KB_NB : 0);
 }
 
 // Explicit unitary factors, columns spread over gridDim.x workgroups per item and matrix.

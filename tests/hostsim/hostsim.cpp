@@ -27,6 +27,26 @@ static HostCtx make_ctx(std::vector<char>& arena, size_t bytes) {
     return c;
 }
 
+// blocked bidiagonalisation exactly as the kernels sequence it: panels + trailing updates + tail
+static void hs_bidiag_blocked(HostCtx& ctx, int m, cd* A, double* d, double* e, cd* tq, cd* tp, cd* UR) {
+    const int npan = bidiag_num_panels(m);
+    std::vector<cd> X((size_t)m * KB_NB), Y((size_t)m * KB_NB);
+    for (int p = 0; p < npan; ++p) {
+        const int p0 = p * KB_NB, n = m - p0;
+        cd* Ab = A + p0 + (size_t)p0 * m;
+        cd* Ub = UR + p0 + (size_t)p0 * m;
+        bidiag_panel(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
+        for (int c = KB_NB; c < n; ++c)
+            for (int r = KB_NB; r < n; ++r) {
+                cd acc = Ab[r + (size_t)c * m];
+                for (int t = 0; t < KB_NB; ++t)
+                    acc = acc - Ab[r + (size_t)t * m] * conj(Y[c + (size_t)t * m]) - X[r + (size_t)t * m] * conj(Ub[c + (size_t)t * m]);
+                Ab[r + (size_t)c * m] = acc;
+            }
+    }
+    bidiag(ctx, m, A, m, d, e, tq, tp, UR, m, npan * KB_NB);
+}
+
 extern "C" {
 
 // A (m x m column-major) -> L (m x m), s (m), R (m x m), A = L diag(s) R^H
@@ -35,9 +55,9 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
     std::vector<double> d(m), e(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) +
+    HostCtx ctx = make_ctx(arena, bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) +
                                       bdsqr_apply_scratch_bytes(m, m) + 4 * m);
-    bidiag(ctx, m, A.data(), m, d.data(), e.data(), tq.data(), tp.data(), UR.data(), m);
+    hs_bidiag_blocked(ctx, m, A.data(), d.data(), e.data(), tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
     int info = 0, nb = 0;
@@ -56,8 +76,8 @@ int hs_bidiag(const double* A_in, int m, double* d, double* e, double* Q_out, do
     std::vector<cd> A(m * m), UR(m * m), tq(m), tp(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_scratch_bytes(m, 1, 1));
-    bidiag(ctx, m, A.data(), m, d, e, tq.data(), tp.data(), UR.data(), m);
+    HostCtx ctx = make_ctx(arena, bidiag_panel_scratch_bytes(m, 1, 1));
+    hs_bidiag_blocked(ctx, m, A.data(), d, e, tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), reinterpret_cast<cd*>(Q_out), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), reinterpret_cast<cd*>(P_out), m, 0, m);
     return 0;
