@@ -26,10 +26,10 @@ KB_HD int gehd2_scratch_bytes(int n, int nwaves, int ws) {
 // Hessenberg reduction: W = Qh H Qh^H, Qh = H_0 ... H_{n-3}; reflector k stored in
 // W[k+2.., k] (v[0] = 1 at row k+1); the subdiagonal W[k+1,k] becomes real.
 template <class C>
-KB_HD void gehd2(const C& ctx, int n, cd* W, int ld, cd* tauh) {
+KB_HD void gehd2(const C& ctx, int n, cd* W, int ld, cd* tauh, int k0 = 0) {
     cd* vv = reinterpret_cast<cd*>(ctx.scratch());
     cd* zp = vv + n;
-    for (int k = 0; k < n - 2; ++k) {
+    for (int k = k0; k < n - 2; ++k) {
         cd* col = &W[(k + 1) + (size_t)k * ld];
         const int nv = n - k - 1;
         double beta;
@@ -49,6 +49,122 @@ KB_HD void gehd2(const C& ctx, int n, cd* W, int ld, cd* tauh) {
         if (ctx.tid() == 0) { tauh[k] = tau; col[0] = mk(beta, 0.0); }
         ctx.sync();
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Blocked Hessenberg reduction.  With  A H_j = A - y_j v_j^H  and  H_j^H (.) = (.) - v_j z_j^H  the
+// matrix after j reflectors of a panel is  A^(j) = A0 - Y_j V_j^H - V_j Z_j^H ,
+//   y_j = tau_j A^(j) v_j ,   z_j = tau_j ((A^(j))^H v_j - v_j (y_j^H v_j)) ,
+// so only the current column is formed explicitly inside a panel of KB_NB columns (two
+// matrix-vector products with the untouched A0 per column), and all columns to the right of the
+// panel receive ONE rank-2NB update afterwards (k_hess_update, FP64 MFMA, all CUs).
+// v_t (panel column t, global column kt = p0 + t): rows > kt+1 stored in W[.., kt], implicit 1 at
+// row kt+1, zero above.
+KB_HD cd hess_vt(const cd* W, int ld, int p0, int r, int t) {
+    const int kt = p0 + t;
+    return (r > kt + 1) ? W[r + (size_t)kt * ld] : ((r == kt + 1) ? mk(1.0, 0.0) : czero());
+}
+KB_HD int hess_panel_scratch_bytes(int n, int nwaves, int ws) {
+    int z = n > nwaves * ws ? n : nwaves * ws;
+    return (n + z + 3 * KB_NB + 8) * (int)sizeof(cd);
+}
+
+template <class C>
+KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* Y, cd* Z, int ldyz) {
+#define W_(r_, c_) W[(r_) + (size_t)(c_) * ld]
+#define Y_(r_, c_) Y[(r_) + (size_t)(c_) * ldyz]
+#define Z_(r_, c_) Z[(r_) + (size_t)(c_) * ldyz]
+    const int tid = ctx.tid(), nt = ctx.nthreads(), lane = ctx.lane();
+    cd* ub = reinterpret_cast<cd*>(ctx.scratch());           // v (indexed by global row)
+    cd* zp = ub + N;
+    const int zcap = N > ctx.nwaves() * C::WS ? N : ctx.nwaves() * C::WS;
+    cd* w1 = zp + zcap;
+    cd* w2 = w1 + KB_NB;
+    cd* w3 = w2 + KB_NB;
+    for (int j = 0; j < KB_NB; ++j) {
+        const int k = p0 + j;
+        // ---- 1. column k of A^(j), all rows
+        for (int r = tid; r < N; r += nt) {
+            cd acc = W_(r, k);
+            for (int t = 0; t < j; ++t)
+                acc = acc - Y_(r, t) * conj(hess_vt(W, ld, p0, k, t)) - hess_vt(W, ld, p0, r, t) * conj(Z_(k, t));
+            W_(r, k) = acc;
+        }
+        ctx.sync();
+        // ---- 2. reflector from rows k+1..N-1
+        double beta;
+        cd tau;
+        larfg(ctx, N - k - 1, &W_(k + 1, k), beta, tau);
+        ctx.sync();
+        for (int r = k + 1 + tid; r < N; r += nt) ub[r] = (r == k + 1) ? mk(1.0, 0.0) : W_(r, k);
+        ctx.sync();
+        if (tid == 0) { tauh[j] = tau; W_(k + 1, k) = mk(beta, 0.0); }
+        // ---- 3. w1 = V^H v, w2 = Z^H v, w3 = Y^H v  (one wavefront per dot product)
+        for (int q = ctx.wave(); q < 3 * j; q += ctx.nwaves()) {
+            const int which = q / j, t = q % j;
+            cd acc = czero();
+            for (int r = k + 1 + lane; r < N; r += C::WS) {
+                const cd a = (which == 0) ? hess_vt(W, ld, p0, r, t) : ((which == 1) ? Z_(r, t) : Y_(r, t));
+                cfmac(acc, a, ub[r]);
+            }
+            acc = ctx.wave_sum(acc);
+            if (lane == 0) { if (which == 0) w1[t] = acc; else if (which == 1) w2[t] = acc; else w3[t] = acc; }
+        }
+        ctx.sync();
+        // ---- 4. y = tau (A0[:, k+1:] v - Y w1 - V w2), all rows; yv = y^H v
+        cd yv;
+        {
+            const int ncols = N - k - 1;
+            const int nw = ctx.nwaves();
+            const int nrc = (N + C::WS - 1) / C::WS;
+            const int ncg = (nrc >= nw) ? 1 : (nw / nrc);
+            const int nslots = nrc * ncg;
+            const cd* Ab = &W_(0, k + 1);
+            for (int slot = ctx.wave(); slot < nslots; slot += nw) {
+                const int rc = slot % nrc, cg = slot / nrc;
+                const int i = rc * C::WS + lane;
+                if (i < N) {
+                    cd acc = czero(), acc1 = czero(), acc2 = czero(), acc3 = czero();
+                    int c = cg;
+                    for (; c + 3 * ncg < ncols; c += 4 * ncg) {
+                        const cd a0 = Ab[i + (size_t)c * ld], a1 = Ab[i + (size_t)(c + ncg) * ld];
+                        const cd a2 = Ab[i + (size_t)(c + 2 * ncg) * ld], a3 = Ab[i + (size_t)(c + 3 * ncg) * ld];
+                        cfma(acc, a0, ub[k + 1 + c]); cfma(acc1, a1, ub[k + 1 + c + ncg]);
+                        cfma(acc2, a2, ub[k + 1 + c + 2 * ncg]); cfma(acc3, a3, ub[k + 1 + c + 3 * ncg]);
+                    }
+                    for (; c < ncols; c += ncg) cfma(acc, Ab[i + (size_t)c * ld], ub[k + 1 + c]);
+                    zp[cg * N + i] = (acc + acc1) + (acc2 + acc3);
+                }
+            }
+            ctx.sync();
+            cd part = czero();
+            for (int r = tid; r < N; r += nt) {
+                cd h = czero();
+                for (int g = 0; g < ncg; ++g) h += zp[g * N + r];
+                for (int t = 0; t < j; ++t) h = h - Y_(r, t) * w1[t] - hess_vt(W, ld, p0, r, t) * w2[t];
+                const cd y = tau * h;
+                Y_(r, j) = y;
+                if (r >= k + 1) cfmac(part, y, ub[r]);
+            }
+            yv = ctx.block_sum(part);
+        }
+        // ---- 5. z = tau (A0[k+1:, k+1:]^H v - V w3 - Z w1 - v yv), columns k+1..N-1
+        for (int c = k + 1 + ctx.wave(); c < N; c += ctx.nwaves()) {
+            cd g = czero(), g1 = czero();
+            int r = k + 1 + lane;
+            for (; r + C::WS < N; r += 2 * C::WS) { cfmac(g, W_(r, c), ub[r]); cfmac(g1, W_(r + C::WS, c), ub[r + C::WS]); }
+            for (; r < N; r += C::WS) cfmac(g, W_(r, c), ub[r]);
+            cd corr = czero();
+            for (int t = lane; t < j; t += C::WS) corr = corr + hess_vt(W, ld, p0, c, t) * w3[t] + Z_(c, t) * w1[t];
+            g = ctx.wave_sum((g + g1) - corr);
+            if (lane == 0) Z_(c, j) = tau * (g - ub[c] * yv);
+        }
+        for (int c = tid; c <= k; c += nt) Z_(c, j) = czero();
+        ctx.sync();
+    }
+#undef W_
+#undef Y_
+#undef Z_
 }
 
 // Extract the upper Hessenberg part of W into the work copy Hc that the QR iteration destroys

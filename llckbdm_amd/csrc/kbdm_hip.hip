@@ -110,6 +110,7 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_apply), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_sort), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     return KBDM_OK;
@@ -344,10 +345,20 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     hipStream_t st = ctx->stream;
     const int* perm = pl->d_perm + ch.first;
     {
+        const int npan = (env_int("KBDM_BLOCKED", 1) != 0) ? bidiag_num_panels(ch.lmax) : 0;
+        const int smp = KB_RED_BYTES + hess_panel_scratch_bytes(ch.lmax, ctx->nt_fac / 64, 64);
+        if (npan > 0 && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg panel scratch");
+        for (int pnl = 0; pnl < npan; ++pnl) {
+            hipLaunchKernelGGL(k_hess_panel, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
+                               pl->d_arena, pl->d_varena, pnl, smp);
+            const int ncol = ch.lmax - (pnl + 1) * KB_NB;
+            hipLaunchKernelGGL(k_hess_update, dim3((ch.lmax + 63) / 64, (ncol + 63) / 64, ch.count), dim3(256), 0, st,
+                               pl->d_items, perm, pl->d_arena, pnl);
+        }
         const int sm = KB_RED_BYTES + gehd2_scratch_bytes(ch.lmax, ctx->nt_fac / 64, 64);
         if (sm > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg scratch");
         hipLaunchKernelGGL(k_hess, dim3(ch.count), dim3(ctx->nt_fac), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, sm);
+                           pl->d_varena, sm, npan > 0 ? 1 : 0);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     // Qh is first needed by k_gemm<3>: accumulate it on the side stream while the QR iteration runs.

@@ -413,10 +413,88 @@ __global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, 
 
 
 // ------------------------------------------------------------------------------------
-// Hessenberg reduction of W (in KB_BUF_P), Qh -> KB_BUF_Q, work copy -> KB_BUF_H,
-// ||H||_inf -> varena.
+// Blocked Hessenberg reduction of W (KB_BUF_P): for panel p = 0, 1, ... (host loop)
+//   k_hess_panel   one workgroup per item: NB reflectors, Y -> KB_BUF_Q, Z -> KB_BUF_H
+//   k_hess_update  all CUs: W[:, p0+NB:] -= [Y | V] [V | Z]^H  (FP64 MFMA tiles)
+// then k_hess finishes unblocked, extracts the work copy (KB_BUF_H) and ||H||_inf.
+__global__ void __launch_bounds__(1024) k_hess_panel(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                      cd* arena, double* varena, int panel, int smem_bytes) {
+    const KbItem it = items[perm[blockIdx.x]];
+    const int n = it.l;
+    if (panel >= bidiag_num_panels(n)) return;
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const int p0 = panel * KB_NB;
+    cd* W = arena + it.off[KB_BUF_P];
+    cd* Y = arena + it.off[KB_BUF_Q];
+    cd* Z = arena + it.off[KB_BUF_H];
+    cd* tauh = reinterpret_cast<cd*>(varena + it.voff + KB_V_TAUQ * it.vstride) + p0;
+    hess_panel(ctx, n, W, n, p0, tauh, Y, Z, n);
+}
+
+__global__ void __launch_bounds__(256) k_hess_update(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                      cd* arena, int panel) {
+    const KbItem it = items[perm[blockIdx.z]];
+    const int n = it.l;
+    if (panel >= bidiag_num_panels(n)) return;
+    const int p0 = panel * KB_NB;
+    const int cbase = p0 + KB_NB;                 // first updated column
+    const int ncol = n - cbase;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x * 64 >= n || blockIdx.y * 64 >= ncol) return;
+    const int r0 = blockIdx.x * 64 + (wave & 1) * 32;            // global row
+    const int c0 = cbase + blockIdx.y * 64 + (wave >> 1) * 32;   // global column
+    cd* W = arena + it.off[KB_BUF_P];
+    const cd* Y = arena + it.off[KB_BUF_Q];
+    const cd* Z = arena + it.off[KB_BUF_H];
+    const int li = lane & 15, lk = lane >> 4;
+    kb_d4 acc_re[2][2], acc_im[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
+    for (int k0 = 0; k0 < 2 * KB_NB; k0 += 4) {
+        const int k = k0 + lk;
+        const bool second = k >= KB_NB;
+        const int kk = second ? k - KB_NB : k;
+        cd av[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int r = r0 + a * 16 + li;
+            const int c = c0 + a * 16 + li;
+            // Aop = [Y | V],  Bop = [V | Z]
+            av[a] = (r < n) ? (second ? hess_vt(W, n, p0, r, kk) : Y[r + (size_t)kk * n]) : czero();
+            bv[a] = (c < n) ? (second ? Z[c + (size_t)kk * n] : hess_vt(W, n, p0, c, kk)) : czero();
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].x, acc_re[cb][rb], 0, 0, 0);
+                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].y, av[rb].y, acc_re[cb][rb], 0, 0, 0);
+                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].y, acc_im[cb][rb], 0, 0, 0);
+                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bv[cb].y, av[rb].x, acc_im[cb][rb], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + rb * 16 + li;
+                const int c = c0 + cb * 16 + lk + 4 * g;
+                if (r < n && c < n) {
+                    cd* pc = &W[r + (size_t)c * n];
+                    cd v = *pc;
+                    v.x -= acc_re[cb][rb][g];
+                    v.y -= acc_im[cb][rb][g];
+                    *pc = v;
+                }
+            }
+}
+
 __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                cd* arena, double* varena, int smem_bytes) {
+                                                cd* arena, double* varena, int smem_bytes, int blocked) {
     const KbItem it = items[perm[blockIdx.x]];
     const DevCtx ctx = make_ctx(smem_bytes);
     const int n = it.l;
@@ -424,7 +502,7 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
     cd* Hc = arena + it.off[KB_BUF_H];
     double* dv = varena + it.voff;
     cd* tauh = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);   // tauq is dead by now
-    gehd2(ctx, n, W, n, tauh);
+    gehd2(ctx, n, W, n, tauh, blocked ? bidiag_num_panels(n) * KB_NB : 0);
     hess_copy(ctx, n, W, n, Hc, n);
     double rmax = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {

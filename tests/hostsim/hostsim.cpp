@@ -88,9 +88,25 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     std::vector<cd> W(n * n), Qh(n * n), Hc(n * n), Ht(n * n), X(n * n), th(n);
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n) +
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hess_panel_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n) +
                                       hqr_win_scratch_bytes(8, 60, 1));
-    gehd2(ctx, n, W.data(), n, th.data());
+    {   // blocked Hessenberg reduction as the kernels sequence it: panels + updates + tail
+        const int npan = bidiag_num_panels(n);
+        std::vector<cd> Yp((size_t)n * KB_NB), Zp((size_t)n * KB_NB);
+        for (int pnl = 0; pnl < npan; ++pnl) {
+            const int p0 = pnl * KB_NB;
+            hess_panel(ctx, n, W.data(), n, p0, th.data() + p0, Yp.data(), Zp.data(), n);
+            for (int c = p0 + KB_NB; c < n; ++c)
+                for (int r = 0; r < n; ++r) {
+                    cd acc = W[r + (size_t)c * n];
+                    for (int t = 0; t < KB_NB; ++t)
+                        acc = acc - Yp[r + (size_t)t * n] * conj(hess_vt(W.data(), n, p0, c, t)) -
+                              hess_vt(W.data(), n, p0, r, t) * conj(Zp[c + (size_t)t * n]);
+                    W[r + (size_t)c * n] = acc;
+                }
+        }
+        gehd2(ctx, n, W.data(), n, th.data(), npan * KB_NB);
+    }
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, n, n - 2, 1, W.data(), n, th.data(), Qh.data(), n, 0, n);
     hess_copy(ctx, n, W.data(), n, Hc.data(), n);
     // infinity norm of H (zhsein: hnorm = zlanhs('I'))
