@@ -392,7 +392,11 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
         }
         ctx.sync();
         const long long c_b = KB_CLOCK();
-        // ---- (b) chase inside the window, logging the reflectors
+        // ---- (b) chase inside the window, logging the reflectors.  Bulge positions are arithmetic
+        // (k = l + t - 3 b), so the reflector-table read and the matrix reads are independent LDS loads;
+        // the item -> (bulge, offset) split of the first pass is hoisted out of the interval loop.
+        const int q0 = tid / W, r0 = tid % W;
+        const int cmax = (i < we - 1) ? i : we - 1;
         for (int t = t0; t < t1; ++t) {
             int b_hi = t / 3;
             if (b_hi > ns - 1) b_hi = ns - 1;
@@ -421,30 +425,35 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
             ctx.sync();
             const int nb = b_hi - b_lo + 1;
             // rows k, k+1 ; columns k..min(i, we-1)
-            const int cmax = (i < we - 1) ? i : we - 1;
             for (int idx = tid; idx < nb * W; idx += nt) {
-                const int b = b_lo + idx / W;
-                const MsRefl rf = refl[b];
-                const int j = rf.k + idx % W;
+                int q = q0, o = r0;
+                if (idx != tid) { q = idx / W; o = idx % W; }
+                const int b = b_lo + q;
+                const int k = l + t - 3 * b;
+                const int j = k + o;
                 if (j <= cmax) {
-                    const cd a = HW(rf.k, j), bb = HW(rf.k + 1, j);
-                    const cd sum = conj(rf.t1) * a + conj(rf.t2) * bb;
-                    HW(rf.k, j) = a - sum;
-                    HW(rf.k + 1, j) = bb - sum * rf.v2;
+                    const cd t1c = refl[b].t1, t2c = refl[b].t2, v2c = refl[b].v2;
+                    const cd a = HW(k, j), bb = HW(k + 1, j);
+                    const cd sum = conj(t1c) * a + conj(t2c) * bb;
+                    HW(k, j) = a - sum;
+                    HW(k + 1, j) = bb - sum * v2c;
                 }
             }
             ctx.sync();
-            // columns k, k+1 ; rows ws'..min(k+2, i)   (ws' = max(l, ws) = ws)
+            // columns k, k+1 ; rows ws..min(k+2, i)
             for (int idx = tid; idx < nb * W; idx += nt) {
-                const int b = b_lo + idx / W;
-                const MsRefl rf = refl[b];
-                const int rmax = (rf.k + 2 < i) ? rf.k + 2 : i;
-                const int r = ws + idx % W;
+                int q = q0, o = r0;
+                if (idx != tid) { q = idx / W; o = idx % W; }
+                const int b = b_lo + q;
+                const int k = l + t - 3 * b;
+                const int rmax = (k + 2 < i) ? k + 2 : i;
+                const int r = ws + o;
                 if (r <= rmax) {
-                    const cd a = HW(r, rf.k), bb = HW(r, rf.k + 1);
-                    const cd sum = rf.t1 * a + rf.t2 * bb;
-                    HW(r, rf.k) = a - sum;
-                    HW(r, rf.k + 1) = bb - sum * conj(rf.v2);
+                    const cd t1c = refl[b].t1, t2c = refl[b].t2, v2c = conj(refl[b].v2);
+                    const cd a = HW(r, k), bb = HW(r, k + 1);
+                    const cd sum = t1c * a + t2c * bb;
+                    HW(r, k) = a - sum;
+                    HW(r, k + 1) = bb - sum * v2c;
                 }
             }
             ctx.sync();

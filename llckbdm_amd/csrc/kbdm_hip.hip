@@ -460,7 +460,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     if (c->win_hqr > 0 && c->win_hqr < 3 * c->ns_hqr + 8) c->win_hqr = 3 * c->ns_hqr + 8;
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
-    if (c->nt_hqr > 1024) c->nt_hqr = 1024;
+    if (c->nt_hqr > 512) c->nt_hqr = 512;
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
     int r = set_lds_attr();
     if (r) { delete c; return r; }

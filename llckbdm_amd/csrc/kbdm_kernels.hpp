@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
     if (threadIdx.x == 0) dv[KB_V_MISC * it.vstride] = rmax;
 }
 
-__global__ void __launch_bounds__(1024) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
+__global__ void __launch_bounds__(512) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                cd* arena, double* varena, cd* mu_out, int* status,
                                                int smem_bytes, int nsmax, int win_w, MsStats* prof) {
     const int item = perm[blockIdx.x];
