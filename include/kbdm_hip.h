@@ -86,6 +86,10 @@ int kbdm_plan_copy_lines_device(kbdm_plan* plan, void* dst_device, int64_t dst_b
  * also returns the kernel names through kbdm_stage_name */
 int kbdm_plan_stage_ms(kbdm_plan* plan, float* ms, int n);
 const char* kbdm_stage_name(int stage);
+/* A plan runs its members in concurrent "lanes" (sub-batches by size, largest members in lane 0,
+ * each an in-order pipeline on its own HIP stream).  The stage timers above are lane 0's: the
+ * critical path.  Returns the number of members (the largest ones) that lane 0 holds. */
+int kbdm_plan_lane0_members(const kbdm_plan* plan);
 
 /* One-shot: plan + upload + execute + download.  line_off/sv_off (B+1) are outputs. */
 int kbdm_solve_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B,

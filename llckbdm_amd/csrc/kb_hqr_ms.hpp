@@ -104,9 +104,9 @@ KB_HD void single_shift_sweep(const C& ctx, cd* H, int ld, int l, int i, int kde
     const int tid = ctx.tid(), nt = ctx.nthreads();
     cd t;
     if (kdefl % 20 == 0) {
-        t = mk(0.75 * fabs(HH(i, i - 1).x), 0.0) + HH(i, i);
+        t = mk(0.75 * cabs1(HH(i, i - 1)), 0.0) + HH(i, i);
     } else if (kdefl % 10 == 0) {
-        t = mk(0.75 * fabs(HH(l + 1, l).x), 0.0) + HH(l, l);
+        t = mk(0.75 * cabs1(HH(l + 1, l)), 0.0) + HH(l, l);
     } else {
         t = HH(i, i);
         const cd u = csqrt_(HH(i - 1, i)) * csqrt_(HH(i, i - 1));
@@ -128,12 +128,12 @@ KB_HD void single_shift_sweep(const C& ctx, cd* H, int ld, int l, int i, int kde
     for (int mm = l + 1 + tid; mm <= i - 1; mm += nt) {
         const cd h11 = HH(mm, mm), h22 = HH(mm + 1, mm + 1);
         cd h11s = h11 - t;
-        double h21 = HH(mm + 1, mm).x;
-        const double s = cabs1(h11s) + fabs(h21);
+        double h21 = cabs1(HH(mm + 1, mm));
+        const double s = cabs1(h11s) + h21;
         h11s = mk(h11s.x / s, h11s.y / s);
         h21 = h21 / s;
-        const double h10 = HH(mm, mm - 1).x;
-        if (fabs(h10) * fabs(h21) <= ulp * (cabs1(h11s) * (cabs1(h11) + cabs1(h22))))
+        const double h10 = cabs1(HH(mm, mm - 1));
+        if (h10 * h21 <= ulp * (cabs1(h11s) * (cabs1(h11) + cabs1(h22))))
             if (mm > mf) mf = mm;
     }
     mf = ctx.block_max(mf);
@@ -141,21 +141,28 @@ KB_HD void single_shift_sweep(const C& ctx, cd* H, int ld, int l, int i, int kde
     cd v1, v2;
     {
         cd h11s = HH(ms, ms) - t;
-        double h21 = HH(ms + 1, ms).x;
-        const double s = cabs1(h11s) + fabs(h21);
+        const cd h21 = HH(ms + 1, ms);
+        const double s = cabs1(h11s) + cabs1(h21);
         v1 = mk(h11s.x / s, h11s.y / s);
-        v2 = mk(h21 / s, 0.0);
+        v2 = mk(h21.x / s, h21.y / s);
     }
     for (int k = ms; k <= i - 1; ++k) {
         if (k > ms) { v1 = HH(k, k - 1); v2 = HH(k + 1, k - 1); }
         cd t1;
         larfg2(v1, v2, t1);
         ctx.sync();
-        if (k > ms && tid == 0) { HH(k, k - 1) = v1; HH(k + 1, k - 1) = czero(); }
-        const double t2 = (t1 * v2).x;
+        if (tid == 0) {
+            if (k > ms) { HH(k, k - 1) = v1; HH(k + 1, k - 1) = czero(); }
+            // started below the top of the block (two consecutive small subdiagonals): row ms of the
+            // neglected column ms-1 still takes its factor; the fill-in below it is the neglected product
+            else if (ms > l) HH(ms, ms - 1) = HH(ms, ms - 1) * (mk(1.0, 0.0) - conj(t1));
+        }
+        // subdiagonals are general complex numbers here (the multishift chase leaves H(i,i-1)
+        // complex), so is t2 = t1 v2
+        const cd t2 = t1 * v2;
         for (int j = k + tid; j <= i; j += nt) {
             const cd a = HH(k, j), b = HH(k + 1, j);
-            const cd sum = conj(t1) * a + t2 * b;
+            const cd sum = conj(t1) * a + conj(t2) * b;
             HH(k, j) = a - sum;
             HH(k + 1, j) = b - sum * v2;
         }
@@ -168,31 +175,6 @@ KB_HD void single_shift_sweep(const C& ctx, cd* H, int ld, int l, int i, int kde
             HH(j, k + 1) = b - sum * conj(v2);
         }
         ctx.sync();
-        if (k == ms && ms > l) {
-            cd temp = mk(1.0, 0.0) - t1;
-            const double at = cabs(temp);
-            temp = mk(temp.x / at, temp.y / at);
-            if (tid == 0) {
-                HH(ms + 1, ms) = HH(ms + 1, ms) * conj(temp);
-                if (ms + 2 <= i) HH(ms + 2, ms + 1) = HH(ms + 2, ms + 1) * temp;
-            }
-            ctx.sync();
-            const int len = i - l + 1;
-            for (int idx = tid; idx < len * len; idx += nt) {
-                const int r = l + idx % len, c = l + idx / len;
-                if (r < c) {
-                    const bool rin = (r >= ms && r != ms + 1);
-                    const bool cin = (c >= ms && c != ms + 1);
-                    if (rin || cin) {
-                        cd v = HH(r, c);
-                        if (rin) v = v * temp;
-                        if (cin) v = v * conj(temp);
-                        HH(r, c) = v;
-                    }
-                }
-            }
-            ctx.sync();
-        }
     }
 #undef HH
 }
@@ -630,22 +612,7 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
         ctx.sync();
         return;
     }
-    // make every subdiagonal real (diagonal unitary similarity; eigenvalues unchanged)
-    for (int i = 1; i < n; ++i) {
-        ctx.sync();
-        const cd hs = HH(i, i - 1);
-        if (hs.y != 0.0) {
-            const double a = cabs(hs);
-            const cd sc = mk(hs.x / a, -hs.y / a);
-            ctx.sync();
-            if (tid == 0) {
-                HH(i, i - 1) = mk(a, 0.0);
-                if (i + 1 < n) HH(i + 1, i) = HH(i + 1, i) * conj(sc);
-            }
-            for (int j = i + 1 + tid; j < n; j += nt) HH(i, j) = HH(i, j) * sc;
-            for (int r = tid; r < i; r += nt) HH(r, i) = HH(r, i) * conj(sc);
-        }
-    }
+    // (subdiagonals stay general complex numbers throughout: no realness is maintained)
     ctx.sync();
     const int itmax = 30 * (n > 10 ? n : 10);
     int kdefl = 0;
@@ -665,10 +632,10 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
                 else {
                     double tst = cabs1(HH(k - 1, k - 1)) + cabs1(HH(k, k));
                     if (tst == 0.0) {
-                        if (k - 2 >= 0) tst += fabs(HH(k - 1, k - 2).x);
-                        if (k + 1 <= n - 1) tst += fabs(HH(k + 1, k).x);
+                        if (k - 2 >= 0) tst += cabs1(HH(k - 1, k - 2));
+                        if (k + 1 <= n - 1) tst += cabs1(HH(k + 1, k));
                     }
-                    if (fabs(hkk1.x) <= ulp * tst) {
+                    if (cabs1(hkk1) <= ulp * tst) {
                         const double a1 = cabs1(hkk1), a2 = cabs1(HH(k - 1, k));
                         const double ab = fmax(a1, a2), ba = fmin(a1, a2);
                         const cd df = HH(k - 1, k - 1) - HH(k, k);
@@ -734,18 +701,6 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
                 else
                     chase_global(ctx, H, ld, l, i, ns, sh, refl);
                 if (stats && tid == 0) { stats->intervals += T; stats->batches++; }
-            }
-            // ---- ensure H(i, i-1) is real
-            {
-                cd temp = HH(i, i - 1);
-                ctx.sync();
-                if (temp.y != 0.0) {
-                    const double rt = cabs(temp);
-                    if (tid == 0) HH(i, i - 1) = mk(rt, 0.0);
-                    temp = mk(temp.x / rt, temp.y / rt);
-                    for (int r = l + tid; r <= i - 1; r += nt) HH(r, i) = HH(r, i) * temp;
-                    ctx.sync();
-                }
             }
         }
         ctx.sync();

@@ -46,11 +46,23 @@ const char* kStageNames[KBDM_NSTAGES] = {"k_hankel",  "k_svd_fac", "k_gen(Q,P)",
 
 }  // namespace
 
-struct kbdm_ctx {
-    int device = 0;
+// A lane = one in-order pipeline (main stream + side stream).  The members of a batch are split
+// over the lanes by size, so that the throughput-bound stages of the small members run underneath
+// the latency-bound stages (one CU per member) of the large ones.
+struct Lane {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: work that is independent of the main chain
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
+};
+
+#define KB_MAX_LANES 8
+
+struct kbdm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;             // = lanes[0].stream: the stream the C ABI synchronises on
+    Lane lanes[KB_MAX_LANES];
+    hipEvent_t ev_start = nullptr;
+    int nlanes = 2;
     int nt_fac = 1024;    // threads per workgroup: bidiagonalisation / Hessenberg kernels
     int nt_bdsqr = 1024;
     int nt_hqr = 512;
@@ -65,6 +77,8 @@ struct kbdm_ctx {
 struct Chunk {
     int first = 0, count = 0;   // range in sorted order
     int mmax = 0, lmax = 0;
+    int group = 0;              // workspace generation: groups run one after the other (they share the arena)
+    int lane = 0;               // chunks of one group run concurrently, one per lane
     std::vector<hipEvent_t> ev;
 };
 
@@ -118,7 +132,7 @@ int set_lds_attr() {
 
 // Build items / order / chunks / device descriptors.  mode: 0 = full pipeline,
 // 1 = stage API (dense m*m host layouts, hk_off).
-int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const int32_t* l) {
+int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const int32_t* l, int nlanes = 1) {
     kbdm_ctx* ctx = pl->ctx;
     const int B = pl->B;
     pl->items.resize(B);
@@ -189,6 +203,33 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
         pl->varena_elems = std::max(pl->varena_elems, vused);
     }
     if (cur.count > 0) pl->chunks.push_back(cur);
+    for (size_t g = 0; g < pl->chunks.size(); ++g) pl->chunks[g].group = (int)g;
+    // split every group into lanes of (about) equal cost, largest members in lane 0
+    if (nlanes > 1) {
+        std::vector<Chunk> out;
+        for (const Chunk& g : pl->chunks) {
+            int nl = std::min(nlanes, g.count / 4);
+            if (nl < 2) { out.push_back(g); continue; }
+            double total = 0.0;
+            for (int k = 0; k < g.count; ++k) { const double mm = pl->items[pl->perm[g.first + k]].m; total += mm * mm * mm; }
+            int pos = 0;
+            double acc = 0.0;
+            for (int ln = 0; ln < nl; ++ln) {
+                Chunk c;
+                c.group = g.group; c.lane = ln; c.first = g.first + pos;
+                const double upto = total * (ln + 1) / nl;
+                while (pos < g.count && (ln == nl - 1 || acc < upto || c.count == 0)) {
+                    const KbItem& it = pl->items[pl->perm[g.first + pos]];
+                    acc += (double)it.m * it.m * it.m;
+                    c.mmax = std::max(c.mmax, it.m);
+                    c.lmax = std::max(c.lmax, it.l);
+                    c.count++; pos++;
+                }
+                if (c.count > 0) out.push_back(c);
+            }
+        }
+        pl->chunks.swap(out);
+    }
     return KBDM_OK;
 }
 
@@ -221,12 +262,12 @@ struct StageTimer {
             ch->ev.resize(KBDM_NSTAGES + 1);
             for (auto& e : ch->ev) HIPCHK(hipEventCreate(&e));
         }
-        HIPCHK(hipEventRecord(ch->ev[0], pl->ctx->stream));
+        HIPCHK(hipEventRecord(ch->ev[0], pl->ctx->lanes[ch->lane].stream));
         idx = 1;
         return KBDM_OK;
     }
     int mark() {
-        HIPCHK(hipEventRecord(ch->ev[idx], pl->ctx->stream));
+        HIPCHK(hipEventRecord(ch->ev[idx], pl->ctx->lanes[ch->lane].stream));
         idx++;
         return KBDM_OK;
     }
@@ -251,7 +292,8 @@ int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream
 
 int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     kbdm_ctx* ctx = pl->ctx;
-    hipStream_t st = ctx->stream;
+    Lane& ln = ctx->lanes[ch.lane];
+    hipStream_t st = ln.stream;
     const int* perm = pl->d_perm + ch.first;
     {
         // blocked part: panels + MFMA trailing updates (all inside the "k_svd_fac" stage timer)
@@ -275,14 +317,14 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     // The scalar QR iteration needs only (d, e): it runs on the side stream while the main
     // stream accumulates Q and P.  (Its stage timer therefore shows ~0; k_gen(Q,P)'s slot spans
     // max(k_gen, k_bdsqr_gen).)
-    HIPCHK(hipEventRecord(ctx->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    HIPCHK(hipEventRecord(ln.ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(ln.stream2, ln.ev_fork, 0));
     {
         const int sm = KB_RED_BYTES + bdsqr_gen_scratch_bytes(ch.mmax);
         if (sm > LDS_MAX - 64) return fail(KBDM_E_NOMEM, "m too large for the bidiagonal QR scratch");
-        hipLaunchKernelGGL(k_bdsqr_gen, dim3(ch.count), dim3(64), sm, ctx->stream2, pl->d_items, perm, pl->d_varena,
+        hipLaunchKernelGGL(k_bdsqr_gen, dim3(ch.count), dim3(64), sm, ln.stream2, pl->d_items, perm, pl->d_varena,
                            pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
-        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));
     }
     // In-kernel hand-off (DONE flag per item) lets the replay of small members start while the
     // generators of large members are still running.  Only when every generator wavefront is
@@ -292,7 +334,7 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     {
         int r = launch_gen(pl, ch, ch.mmax, 0, 2, st);
         if (r) return r;
-        if (!flag_mode) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        if (!flag_mode) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
         if (tm) { r = tm->mark(); if (r) return r; }
         if (tm) { r = tm->mark(); if (r) return r; }      // k_bdsqr_gen slot (overlapped)
     }
@@ -327,7 +369,7 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             hipLaunchKernelGGL(k_bdsqr_apply, dim3(bk.groups, bk.cnt, 2), dim3(64), bk.sm, st, pl->d_items,
                                perm + bk.pos, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, bk.sm, flag_mode ? 1 : 0);
         }
-        if (flag_mode) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        if (flag_mode) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
@@ -342,7 +384,8 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
 
 int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     kbdm_ctx* ctx = pl->ctx;
-    hipStream_t st = ctx->stream;
+    Lane& ln = ctx->lanes[ch.lane];
+    hipStream_t st = ln.stream;
     const int* perm = pl->d_perm + ch.first;
     {
         const int npan = (env_int("KBDM_BLOCKED", 1) != 0) ? bidiag_num_panels(ch.lmax) : 0;
@@ -362,12 +405,12 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     // Qh is first needed by k_gemm<3>: accumulate it on the side stream while the QR iteration runs.
-    HIPCHK(hipEventRecord(ctx->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    HIPCHK(hipEventRecord(ln.ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(ln.stream2, ln.ev_fork, 0));
     {
-        int r = launch_gen(pl, ch, ch.lmax, 1, 1, ctx->stream2);
+        int r = launch_gen(pl, ch, ch.lmax, 1, 1, ln.stream2);
         if (r) return r;
-        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));
         if (tm) { r = tm->mark(); if (r) return r; }      // k_gen(Qh) slot (overlapped with k_hqr)
     }
     {
@@ -405,7 +448,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         const int sm = KB_RED_BYTES + nw * per;
         hipLaunchKernelGGL(k_invit, dim3(ch.count, ctx->split_invit), dim3(ctx->nt_invit), sm, st, pl->d_items, perm,
                            pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm);
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));   // Qh ready before k_gemm<3>
+        HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // Qh ready before k_gemm<3>
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     HIPCHK(hipGetLastError());
@@ -416,8 +459,46 @@ template <int STAGE>
 void launch_gemm(kbdm_plan* pl, Chunk& ch, int Mmax, int Nmax) {
     const int* perm = pl->d_perm + ch.first;
     dim3 grid((Mmax + GT - 1) / GT, (Nmax + GT - 1) / GT, ch.count);
-    hipLaunchKernelGGL(k_gemm<STAGE>, grid, dim3(256), 0, pl->ctx->stream, pl->d_items, perm, pl->d_signals, pl->N,
+    hipLaunchKernelGGL(k_gemm<STAGE>, grid, dim3(256), 0, pl->ctx->lanes[ch.lane].stream, pl->d_items, perm, pl->d_signals, pl->N,
                        pl->p, pl->d_arena, pl->d_varena);
+}
+
+// The whole pipeline of one chunk on its lane's streams.
+int run_chunk(kbdm_plan* pl, Chunk& ch) {
+    hipStream_t st = pl->ctx->lanes[ch.lane].stream;
+    StageTimer tm{pl, &ch};
+    int r = tm.init();
+    if (r) return r;
+    const int* perm = pl->d_perm + ch.first;
+    {   // K1: U^{p-1} into the SVD work buffer
+        HankelOut o0{pl->d_arena, pl->p - 1, KB_BUF_A, 1};
+        HankelOut none{nullptr, 0, 0, 0};
+        const int tiles = (ch.mmax + HK_TILE - 1) / HK_TILE;
+        hipLaunchKernelGGL(k_hankel, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
+                           pl->d_signals, pl->N, 1, o0, none, none);
+        if ((r = tm.mark())) return r;
+    }
+    if ((r = launch_svd(pl, ch, &tm))) return r;
+    launch_gemm<1>(pl, ch, ch.mmax, ch.lmax);
+    if ((r = tm.mark())) return r;
+    launch_gemm<2>(pl, ch, ch.lmax, ch.lmax);
+    if ((r = tm.mark())) return r;
+    if ((r = launch_eig(pl, ch, &tm))) return r;
+    launch_gemm<3>(pl, ch, ch.lmax, ch.lmax);
+    if ((r = tm.mark())) return r;
+    launch_gemm<4>(pl, ch, ch.mmax, ch.lmax);
+    if ((r = tm.mark())) return r;
+    launch_gemm<5>(pl, ch, ch.mmax, ch.lmax);
+    if ((r = tm.mark())) return r;
+    {
+        const int wpb = 4;
+        dim3 grid((ch.lmax + wpb - 1) / wpb, ch.count);
+        hipLaunchKernelGGL(k_epilogue, grid, dim3(64 * wpb), 0, st, pl->d_items, perm, pl->d_signals, pl->N,
+                           pl->d_arena, pl->d_mu, pl->dwell, pl->d_lines, pl->d_keep);
+        if ((r = tm.mark())) return r;
+    }
+    HIPCHK(hipGetLastError());
+    return KBDM_OK;
 }
 
 }  // namespace
@@ -446,10 +527,22 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     HIPCHK(hipSetDevice(device));
     kbdm_ctx* c = new kbdm_ctx();
     c->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->nlanes = std::min(KB_MAX_LANES, std::max(1, env_int("KBDM_LANES", c->nlanes)));
+    for (int i = 0; i < c->nlanes; ++i) {
+        Lane& ln = c->lanes[i];
+        HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        // Only the critical lane gets a side stream of its own: streams beyond the hardware queue
+        // count share queues, and two lanes whose replay kernels wait (in-kernel flags) on generator
+        // kernels queued behind each other would never finish.  On the other lanes the side work
+        // simply runs in stream order.
+        if (i == 0) HIPCHK(hipStreamCreateWithFlags(&ln.stream2, hipStreamNonBlocking));
+        else ln.stream2 = ln.stream;
+        HIPCHK(hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+    }
+    c->stream = c->lanes[0].stream;
+    HIPCHK(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
     c->nt_fac = env_int("KBDM_NT_FAC", c->nt_fac);
     c->nt_bdsqr = env_int("KBDM_NT_BDSQR", c->nt_bdsqr);
     c->nt_hqr = env_int("KBDM_NT_HQR", c->nt_hqr);
@@ -470,10 +563,15 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
 
 int kbdm_ctx_destroy(kbdm_ctx* ctx) {
     if (!ctx) return KBDM_OK;
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
-    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
-    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    for (int i = 0; i < KB_MAX_LANES; ++i) {
+        Lane& ln = ctx->lanes[i];
+        if (ln.stream2 && ln.stream2 != ln.stream) hipStreamDestroy(ln.stream2);
+        if (ln.stream) hipStreamDestroy(ln.stream);
+        if (ln.ev_fork) hipEventDestroy(ln.ev_fork);
+        if (ln.ev_join) hipEventDestroy(ln.ev_join);
+        if (ln.ev_done) hipEventDestroy(ln.ev_done);
+    }
+    if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
     delete ctx;
     return KBDM_OK;
 }
@@ -484,7 +582,7 @@ int kbdm_plan_create(kbdm_ctx* ctx, int S, int N, int B, const int32_t* sig_idx,
     HIPCHK(hipSetDevice(ctx->device));
     kbdm_plan* pl = new kbdm_plan();
     pl->ctx = ctx; pl->S = S; pl->N = N; pl->B = B; pl->p = p; pl->q = q; pl->dwell = dwell;
-    int r = plan_build(pl, sig_idx, m, l);
+    int r = plan_build(pl, sig_idx, m, l, ctx->nlanes);
     if (!r) r = plan_alloc(pl);
     if (r) { kbdm_plan_destroy(pl); return r; }
     *out = pl;
@@ -529,39 +627,24 @@ int kbdm_plan_execute(kbdm_plan* pl) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemsetAsync(pl->d_status, 0, sizeof(int) * pl->B, st));
     HIPCHK(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * 4 * pl->B, st));
-    for (auto& ch : pl->chunks) {
-        StageTimer tm{pl, &ch};
-        int r = tm.init();
-        if (r) return r;
-        const int* perm = pl->d_perm + ch.first;
-        {   // K1: U^{p-1} into the SVD work buffer
-            HankelOut o0{pl->d_arena, pl->p - 1, KB_BUF_A, 1};
-            HankelOut none{nullptr, 0, 0, 0};
-            const int tiles = (ch.mmax + HK_TILE - 1) / HK_TILE;
-            hipLaunchKernelGGL(k_hankel, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
-                               pl->d_signals, pl->N, 1, o0, none, none);
-            if ((r = tm.mark())) return r;
+    // groups one after the other (they share the arena); inside a group one chunk per lane, all
+    // lanes concurrently: fork from the main stream, join back into it
+    size_t ci = 0;
+    while (ci < pl->chunks.size()) {
+        size_t ce = ci;
+        while (ce < pl->chunks.size() && pl->chunks[ce].group == pl->chunks[ci].group) ++ce;
+        HIPCHK(hipEventRecord(ctx->ev_start, st));
+        for (size_t c = ci; c < ce; ++c) {
+            Chunk& ch = pl->chunks[c];
+            hipStream_t ls = ctx->lanes[ch.lane].stream;
+            if (ch.lane != 0) HIPCHK(hipStreamWaitEvent(ls, ctx->ev_start, 0));
+            int r = run_chunk(pl, ch);
+            if (r) return r;
+            if (ch.lane != 0) HIPCHK(hipEventRecord(ctx->lanes[ch.lane].ev_done, ls));
         }
-        if ((r = launch_svd(pl, ch, &tm))) return r;
-        launch_gemm<1>(pl, ch, ch.mmax, ch.lmax);
-        if ((r = tm.mark())) return r;
-        launch_gemm<2>(pl, ch, ch.lmax, ch.lmax);
-        if ((r = tm.mark())) return r;
-        if ((r = launch_eig(pl, ch, &tm))) return r;
-        launch_gemm<3>(pl, ch, ch.lmax, ch.lmax);
-        if ((r = tm.mark())) return r;
-        launch_gemm<4>(pl, ch, ch.mmax, ch.lmax);
-        if ((r = tm.mark())) return r;
-        launch_gemm<5>(pl, ch, ch.mmax, ch.lmax);
-        if ((r = tm.mark())) return r;
-        {
-            const int wpb = 4;
-            dim3 grid((ch.lmax + wpb - 1) / wpb, ch.count);
-            hipLaunchKernelGGL(k_epilogue, grid, dim3(64 * wpb), 0, st, pl->d_items, perm, pl->d_signals, pl->N,
-                               pl->d_arena, pl->d_mu, pl->dwell, pl->d_lines, pl->d_keep);
-            if ((r = tm.mark())) return r;
-        }
-        HIPCHK(hipGetLastError());
+        for (size_t c = ci; c < ce; ++c)
+            if (pl->chunks[c].lane != 0) HIPCHK(hipStreamWaitEvent(st, ctx->lanes[pl->chunks[c].lane].ev_done, 0));
+        ci = ce;
     }
     pl->timed = true;
     return KBDM_OK;
@@ -579,7 +662,7 @@ int kbdm_plan_stage_ms(kbdm_plan* pl, float* ms, int n) {
     for (int s = 0; s < KBDM_NSTAGES; ++s) pl->stage_ms[s] = 0.f;
     if (pl->timed)
         for (auto& ch : pl->chunks) {
-            if (ch.ev.empty()) continue;
+            if (ch.ev.empty() || ch.lane != 0) continue;       // lane 0 holds the largest members: the critical path
             for (int s = 0; s < KBDM_NSTAGES; ++s) {
                 float t = 0.f;
                 HIPCHK(hipEventElapsedTime(&t, ch.ev[s], ch.ev[s + 1]));
@@ -588,6 +671,14 @@ int kbdm_plan_stage_ms(kbdm_plan* pl, float* ms, int n) {
         }
     for (int s = 0; s < n && s < KBDM_NSTAGES; ++s) ms[s] = pl->stage_ms[s];
     return KBDM_OK;
+}
+
+int kbdm_plan_lane0_members(const kbdm_plan* pl) {
+    if (!pl) return 0;
+    int n = 0;
+    for (const auto& ch : pl->chunks)
+        if (ch.lane == 0) n += ch.count;
+    return n;
 }
 
 int kbdm_plan_download(kbdm_plan* pl, double* lines, double* sv, double* mu, uint8_t* keep, int32_t* status) {

@@ -86,6 +86,10 @@ class Plan:
         names = [self.engine.lib.kbdm_stage_name(i).decode() for i in range(_lib.KBDM_NSTAGES)]
         return dict(zip(names, ms.tolist()))
 
+    def lane0_members(self):
+        """Members (the largest ones) in lane 0, whose stage timers `stage_ms` reports."""
+        return int(self.engine.lib.kbdm_plan_lane0_members(self.handle))
+
     def lines_device_ptr(self):
         return self.engine.lib.kbdm_plan_lines_device(self.handle)
 
