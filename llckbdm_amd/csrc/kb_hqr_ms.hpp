@@ -16,7 +16,8 @@
 
 namespace kb {
 
-constexpr int KB_MS_MIN = 12;     // below this active size: single-shift sweeps
+constexpr int KB_MS_MIN = 10;     // below this active size: single-shift sweeps (blocks of at most 9:
+                                  // every element they touch is within KB_TEAM_TOPB of the diagonal)
 constexpr int KB_MS_NSMAX = 32;   // compile-time cap on simultaneous shifts
 constexpr int KB_MS_BU = 4;       // bulges whose loads are batched together
 constexpr int KB_MS_CU = 2;       // row/column chunks per thread batched together
@@ -318,23 +319,403 @@ KB_HD int hqr_win_scratch_bytes(int nsmax, int W, int ws) {
            logcap * (int)sizeof(MsRefl) + 128;
 }
 
+// ---- how the matrix in HBM is addressed.  HPlain: ordinary loads/stores.  HSc1: every access is an
+// sc1 (agent-coherent, L1-bypassing, write-through) buffer access - the flavour a workgroup TEAM uses
+// for all bytes that cross between its workgroups (MI355X_MICROARCH.md, inter-workgroup visibility:
+// sc1 stores + s_waitcnt vmcnt(0) + barrier + sc1 flag / sc1 poll + barrier + sc1 loads).
+struct HPlain {
+    cd* H;
+    int ld;
+    KB_HD cd get(int r, int c) const { return H[r + (size_t)c * ld]; }
+    KB_HD void put(int r, int c, cd v) const { H[r + (size_t)c * ld] = v; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned int kb_u4 __attribute__((ext_vector_type(4)));
+struct HSc1 {
+    __amdgpu_buffer_rsrc_t rs;
+    int ld;
+    __device__ static HSc1 make(cd* H, int ld_, int ncols) {
+        HSc1 a;
+        a.rs = __builtin_amdgcn_make_buffer_rsrc(H, 0, (int)((size_t)ld_ * ncols * sizeof(cd)), 0x00020000);
+        a.ld = ld_;
+        return a;
+    }
+    __device__ cd get(int r, int c) const {
+        const kb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (r + c * ld) * 16, 0, 16);
+        cd o;
+        o.x = __builtin_bit_cast(double, ((unsigned long long)v.y << 32) | v.x);
+        o.y = __builtin_bit_cast(double, ((unsigned long long)v.w << 32) | v.z);
+        return o;
+    }
+    __device__ void put(int r, int c, cd v) const {
+        const unsigned long long a = __builtin_bit_cast(unsigned long long, v.x);
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v.y);
+        const kb_u4 q = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b128(q, rs, (r + c * ld) * 16, 0, 16);
+    }
+};
+#else
+struct HSc1 : HPlain {
+    static HSc1 make(cd* H_, int ld_, int) { HSc1 a; a.H = H_; a.ld = ld_; return a; }
+};
+#endif
+
+// ---- a TEAM = the chase workgroup of a member + one helper workgroup on another CU.
+// The chaser keeps everything within 64 of the diagonal to itself (window, the nearest right tile,
+// the nearest top tile); the helper replays the logged reflectors on the far tiles.  Records
+// (window geometry + reflector log) travel through a small ring in HBM.
+struct TeamCtl {                    // 256 B per member, zeroed before the launch
+    unsigned published;             // chaser: records published so far (monotonic)
+    unsigned done;                  // chaser: no more records will come
+    unsigned abort_;                // anybody: a wait timed out - everyone leaves, status is flagged
+    unsigned pad0[29];
+    unsigned near_done;             // helper: steps g' < near_done have their first round of far right
+                                    //         tiles (and every earlier step entirely) complete
+    unsigned all_done;              // helper: steps g' < all_done are complete
+    unsigned pad1[30];
+};
+struct TeamRec {                    // 64-byte record header, followed by the log (bulge-major)
+    int l, i, ns, na, t0, t1, ws, we, bmin, bmax, nint, g;
+    int pad[4];
+};
+#define KB_TEAM_SLOTS 4
+#define KB_TEAM_TOPB 8              // rows above the window that stay with the chase workgroup
+// What the chase workgroup keeps next to its window: near_r columns to the right, near_t rows above.
+// With 64-lane wavefronts both fit ONE merged tile (lanes 0..55 columns, lanes 56..63 rows).
+template <class C> KB_HD int team_near_r() { return (C::WS >= 64) ? C::WS - KB_TEAM_TOPB : C::WS; }
+template <class C> KB_HD int team_near_t() { return (C::WS >= 64) ? KB_TEAM_TOPB : C::WS; }
+KB_HD int team_rec_bytes(int nsmax, int W) { return (int)sizeof(TeamRec) + (W + 2) * nsmax * (int)sizeof(MsRefl); }
+
+struct WinGeom {
+    int l, i, na, ns, t0, t1, nint, ws, we, wlen, bmin, bmax;
+};
+
 template <class C>
-KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, const cd* sh, MsRefl* refl,
-                          int W, int nsmax, MsStats* stats) {
-#define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
+struct Team;
+
+// Device-side waits: ONE lane polls with sc1 loads (+ s_sleep), result broadcast through LDS.
+// Returns false when the team is aborting.  (Host simulation: the helper runs inline, nothing to wait for.)
+template <class C>
+KB_HD bool team_wait(const C& ctx, volatile unsigned* word, unsigned need, TeamCtl* ctl, int* lds_flag) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ctx.tid() == 0) {
+        int ok = 1;
+        const unsigned long long t_start = wall_clock64();
+        for (;;) {
+            const unsigned v = __hip_atomic_load((unsigned*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v >= need) break;
+            if (__hip_atomic_load(&ctl->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+            if (wall_clock64() - t_start > 1000000000ull) {         // 10 s at 100 MHz: protocol failure
+                __hip_atomic_store(&ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *lds_flag = ok;
+    }
+    ctx.sync();
+    const bool ok = (*lds_flag != 0);
+    ctx.sync();
+    return ok;
+#else
+    (void)ctx; (void)word; (void)need; (void)ctl; (void)lds_flag;
+    return true;
+#endif
+}
+
+// Every wave drains its stores, workgroup barrier, then one lane publishes `value` (sc1 store).
+template <class C>
+KB_HD void team_signal(const C& ctx, unsigned* word, unsigned value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ctx.sync();
+    if (ctx.tid() == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    (void)ctx;
+    *word = value;
+#endif
+}
+
+// Replay of the reflector log on strip tiles staged in LDS (two tiles per round: wavefront w works on
+// tile slot w % 2).  Tiles are numbered by distance from the window:
+//   right tile j : rows ws..we-1, columns we + 64 j ..          (row operations, one lane per column)
+//   top tile j   : columns ws..we-1, rows ws - 64 (j+1) .. ws - 64 j - 1, not above l (column operations,
+//                  one lane per row)
+// Processes right tiles [rlo, rhi) then top tiles [tlo, thi); after_round(r) runs after each round.
+// roff / toff shift the tile grids away from the window (the helper's tiles start beyond the chaser's
+// near region).  MERGED: one single tile holding the chaser's near region (team_near_r columns on the
+// low lanes, team_near_t rows on the high lanes), replayed by all wavefronts.
+template <int MERGED, class C, class ACC, class F>
+KB_HD void strip_tiles(const C& ctx, const ACC& A, const WinGeom& G, const MsRefl* logv, cd* Hw, cd* Tile,
+                       int rlo, int rhi, int tlo, int thi, int roff, int toff, MsStats* stats, F&& after_round) {
+    const int tid = ctx.tid();
+    const int TP = C::WS + 1;
+    const int l = G.l, i = G.i, na = G.na, t0 = G.t0, nint = G.nint, ws = G.ws, we = G.we, wlen = G.wlen;
+    const int bmin = G.bmin, bmax = G.bmax;
+    // With several wavefronts per tile they split its bulges (and its rows for the copies); a bulge on one
+    // wavefront may follow a bulge of another by two intervals on the same rows, hence one workgroup
+    // barrier per interval.  Every wavefront runs the same trip counts (barrier safety).
+    const int ntb = (!MERGED && ctx.nwaves() >= 2) ? 2 : 1;
+    // wavefronts per tile: 1, 2, 4 or 8 (each takes KB_MS_RG / nhalf bulges of every group)
+    const int nhalf = (ctx.nwaves() >= 8 * ntb) ? 8 : (ctx.nwaves() >= 4 * ntb) ? 4 : ((ctx.nwaves() >= 2 * ntb) ? 2 : 1);
+    const int slot = ctx.wave() % ntb, half = ctx.wave() / ntb;
+    const bool worker = ctx.wave() < ntb * nhalf;
+    const int nr = (rhi > rlo) ? rhi - rlo : 0, ntp = (thi > tlo) ? thi - tlo : 0;
+    const int ntiles = MERGED ? ((nr + ntp > 0) ? 1 : 0) : nr + ntp;
+    const int near_r = team_near_r<C>(), near_t = team_near_t<C>();
+    cd* Tl = (slot == 0) ? Hw : Tile;
+    const int lane = ctx.lane();
+    const int ngrp = (bmax - bmin) / KB_MS_RG + 1;
+    for (int round = 0; round * ntb < ntiles; ++round) {
+        const int tile = round * ntb + slot;
+        const bool right = MERGED ? (lane < near_r) : (tile < nr);
+        const int q = MERGED ? (right ? we + lane : ws - near_t + (lane - near_r))
+                             : (right ? we + roff + (rlo + tile) * C::WS : ws - toff - (tlo + tile - nr + 1) * C::WS) + lane;
+        const bool live = worker && tile < ntiles && (right ? (q <= i && nr > 0) : (q >= l && q < ws && ntp > 0));
+        const double sg = right ? -1.0 : 1.0;                // right strip uses conj(t1), conj(t2), v2
+        const long long c_t0 = KB_CLOCK();
+        if (live) {
+            // this wavefront's share of the rows; eight global loads in flight per lane
+            int p = half;
+            for (; p + 7 * nhalf < wlen; p += 8 * nhalf) {
+                cd v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = right ? A.get(ws + p + u * nhalf, q) : A.get(q, ws + p + u * nhalf);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) Tl[(p + u * nhalf) * TP + lane] = v[u];
+            }
+            for (; p < wlen; p += nhalf) Tl[p * TP + lane] = right ? A.get(ws + p, q) : A.get(q, ws + p);
+        }
+        ctx.sync();
+        const long long c_t1 = KB_CLOCK();
+        auto replay = [&](auto nu_tag) {
+            constexpr int NU = decltype(nu_tag)::value;      // bulges handled by this wavefront per group
+            for (int g = 0; g < ngrp; ++g) {
+                const int g0 = g * KB_MS_RG;
+                int tb[NU], te[NU], pp[NU];
+                cd carry[NU];
+                int tt_lo = nint, tt_hi = 0;
+                // interval range of the whole group (uniform over the workgroup)
+                for (int u = 0; u < KB_MS_RG; ++u) {
+                    const int bb_ = bmin + g0 + u;
+                    int b0_ = 3 * bb_ - t0;
+                    if (b0_ < 0) b0_ = 0;
+                    int e0_ = 3 * bb_ + (na - 2) - t0 + 1;
+                    if (e0_ > nint) e0_ = nint;
+                    if (g0 + u <= bmax - bmin && e0_ > b0_) {
+                        tt_lo = b0_ < tt_lo ? b0_ : tt_lo;
+                        tt_hi = e0_ > tt_hi ? e0_ : tt_hi;
+                    }
+                }
+                // the bulges this wavefront replays: local u -> group index
+                const int u_base = half * NU;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int gu = u_base + u;
+                    const int bb_ = bmin + g0 + gu;
+                    int b0_ = 3 * bb_ - t0;
+                    if (b0_ < 0) b0_ = 0;
+                    int e0_ = 3 * bb_ + (na - 2) - t0 + 1;
+                    if (e0_ > nint) e0_ = nint;
+                    if (g0 + gu > bmax - bmin) { b0_ = 0; e0_ = 0; }
+                    tb[u] = b0_; te[u] = e0_;
+                    pp[u] = (l + (t0 + b0_) - 3 * bb_) - ws;
+                    carry[u] = czero();
+                }
+                for (int tt = tt_lo; tt < tt_hi; ++tt) {
+                    if (live) {
+                        // LDS reads of the interval, then the arithmetic, then the writes
+                        cd nbv[NU], c1v[NU], c2v[NU], c3v[NU], outv[NU];
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) {
+                            if (tt >= tb[u] && tt < te[u]) {
+                                const int p = pp[u] + (tt - tb[u]);
+                                const MsRefl* lg = logv + (g0 + u_base + u) * nint + tt;
+                                if (tt == tb[u]) carry[u] = Tl[p * TP + lane];
+                                nbv[u] = Tl[(p + 1) * TP + lane];
+                                const cd t1 = lg->t1, t2 = lg->t2, v2 = lg->v2;
+                                c1v[u] = mk(t1.x, sg * t1.y);
+                                c2v[u] = mk(t2.x, sg * t2.y);
+                                c3v[u] = mk(v2.x, -sg * v2.y);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) {
+                            if (tt >= tb[u] && tt < te[u]) {
+                                const cd sum = c1v[u] * carry[u] + c2v[u] * nbv[u];
+                                outv[u] = carry[u] - sum;
+                                carry[u] = nbv[u] - sum * c3v[u];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) {
+                            if (tt >= tb[u] && tt < te[u]) {
+                                const int p = pp[u] + (tt - tb[u]);
+                                Tl[p * TP + lane] = outv[u];
+                                if (tt == te[u] - 1) Tl[(p + 1) * TP + lane] = carry[u];
+                            }
+                        }
+                    }
+                    if (nhalf > 1) ctx.sync();
+                }
+            }
+        };
+        if (nhalf == 8) replay(KbInt<KB_MS_RG / 8>{});
+        else if (nhalf == 4) replay(KbInt<KB_MS_RG / 4>{});
+        else if (nhalf == 2) replay(KbInt<KB_MS_RG / 2>{});
+        else replay(KbInt<KB_MS_RG>{});
+        ctx.sync();
+        const long long c_t2 = KB_CLOCK();
+        if (live) {
+            for (int p = half; p < wlen; p += nhalf) {
+                if (right) A.put(ws + p, q, Tl[p * TP + lane]);
+                else A.put(q, ws + p, Tl[p * TP + lane]);
+            }
+        }
+        ctx.sync();
+        if (stats && tid == 0) {
+            const long long c_t3 = KB_CLOCK();
+            stats->cyc_tload += c_t1 - c_t0; stats->cyc_treplay += c_t2 - c_t1; stats->cyc_tstore += c_t3 - c_t2;
+            stats->ntiles++;
+        }
+        after_round(round);
+    }
+}
+
+KB_HD void win_tile_counts(const WinGeom& G, int wsz, int roff, int toff, int& tiles_r, int& tiles_t) {
+    int nright = ((G.we <= G.i) ? G.i - G.we + 1 : 0) - roff;
+    int ntop = G.ws - G.l - toff;
+    if (nright < 0) nright = 0;
+    if (ntop < 0) ntop = 0;
+    tiles_r = (nright + wsz - 1) / wsz;
+    tiles_t = (ntop + wsz - 1) / wsz;
+}
+
+// LDS carve shared by the chase workgroup and the helper workgroup (after S, sh, refl, sinfo).
+struct WinLds {
+    cd* Hw;
+    cd* Tile;
+    MsRefl* logv;
+    int* flag;
+};
+template <class C>
+KB_HD WinLds win_lds(const C& ctx, int W, int nsmax) {
+    cd* S = reinterpret_cast<cd*>(ctx.scratch());
+    cd* sh = S + nsmax * nsmax;
+    MsRefl* refl = reinterpret_cast<MsRefl*>(sh + nsmax);
+    int* sinfo = reinterpret_cast<int*>(refl + nsmax);
+    char* base = reinterpret_cast<char*>(refl + nsmax) + 64;   // past refl[nsmax] and the info words
+    const int area = hqr_win_area_elems(W, C::WS);
+    WinLds L;
+    L.Hw = reinterpret_cast<cd*>(base);
+    L.Tile = L.Hw + area;
+    L.logv = reinterpret_cast<MsRefl*>(L.Tile + area);
+    L.flag = sinfo + 4;
+    return L;
+}
+
+template <class C>
+struct Team {
+    TeamCtl* ctl;
+    char* ring;           // KB_TEAM_SLOTS records of rec_bytes each
+    int rec_bytes;
+    unsigned g;           // chaser: global step counter
+    unsigned g_batch;     // chaser: first step of the current batch
+    int failed;           // a wait was aborted
+    HSc1 A;               // the matrix, team flavour
+    int W, nsmax;
+};
+
+// The helper's share of one record: far right tiles (first round reported through near_done), then far
+// top tiles.  Also the body of the host simulation's inline helper.
+template <class C>
+KB_HD void team_helper_record(const C& ctx, Team<C>& tm, const WinGeom& G, unsigned g, const WinLds& L) {
+    const int roff = team_near_r<C>(), toff = team_near_t<C>();
+    int tiles_r, tiles_t;
+    win_tile_counts(G, C::WS, roff, toff, tiles_r, tiles_t);
+    bool near_sent = false;
+    if (tiles_r > 0) {
+        strip_tiles<0>(ctx, tm.A, G, L.logv, L.Hw, L.Tile, 0, tiles_r, 0, 0, roff, toff, nullptr, [&](int round) {
+            if (round == 0) { team_signal(ctx, &tm.ctl->near_done, g + 1); near_sent = true; }
+        });
+    }
+    if (!near_sent) team_signal(ctx, &tm.ctl->near_done, g + 1);
+    if (tiles_t > 0) strip_tiles<0>(ctx, tm.A, G, L.logv, L.Hw, L.Tile, 0, 0, 0, tiles_t, roff, toff, nullptr, [](int) {});
+    team_signal(ctx, &tm.ctl->all_done, g + 1);
+}
+
+// Helper workgroup main loop: consume records until the chaser is done.
+template <class C>
+KB_HD void team_helper_main(const C& ctx, Team<C>& tm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const WinLds L = win_lds(ctx, tm.W, tm.nsmax);
+    const int tid = ctx.tid(), nt = ctx.nthreads();
+    for (unsigned g = 0;; ++g) {
+        // wait for record g or for the end
+        if (tid == 0) {
+            int st = 0;                         // 1: record ready, 2: finished, 3: abort
+            const unsigned long long t_start = wall_clock64();
+            for (;;) {
+                if (__hip_atomic_load(&tm.ctl->published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > g) { st = 1; break; }
+                if (__hip_atomic_load(&tm.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    // done is stored after the last publish: look once more
+                    st = (__hip_atomic_load(&tm.ctl->published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > g) ? 1 : 2;
+                    break;
+                }
+                if (__hip_atomic_load(&tm.ctl->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { st = 3; break; }
+                if (wall_clock64() - t_start > 2000000000ull) {     // 20 s: the chaser is gone
+                    __hip_atomic_store(&tm.ctl->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    st = 3;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            *L.flag = st;
+        }
+        ctx.sync();
+        const int st = *L.flag;
+        ctx.sync();
+        if (st != 1) return;
+        // record -> registers / LDS (sc1 loads)
+        const char* rec = tm.ring + (size_t)(g % KB_TEAM_SLOTS) * tm.rec_bytes;
+        __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rec), 0, tm.rec_bytes, 0x00020000);
+        WinGeom G;
+        {
+            const kb_u4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rr, 0, 0, 16);
+            const kb_u4 h1 = __builtin_amdgcn_raw_buffer_load_b128(rr, 16, 0, 16);
+            const kb_u4 h2 = __builtin_amdgcn_raw_buffer_load_b128(rr, 32, 0, 16);
+            G.l = (int)h0.x; G.i = (int)h0.y; G.ns = (int)h0.z; G.na = (int)h0.w;
+            G.t0 = (int)h1.x; G.t1 = (int)h1.y; G.ws = (int)h1.z; G.we = (int)h1.w;
+            G.bmin = (int)h2.x; G.bmax = (int)h2.y; G.nint = (int)h2.z;
+            G.wlen = G.we - G.ws;
+        }
+        const int nq = (G.bmax - G.bmin + 1) * G.nint * 4;          // 16-byte words of the log
+        kb_u4* dst = reinterpret_cast<kb_u4*>(L.logv);
+        for (int idx = tid; idx < nq; idx += nt)
+            dst[idx] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)sizeof(TeamRec) + idx * 16, 0, 16);
+        ctx.sync();
+        team_helper_record(ctx, tm, G, g, L);
+    }
+#else
+    (void)ctx; (void)tm;
+#endif
+}
+
+template <class C, class ACC>
+KB_HD void chase_windowed(const C& ctx, const ACC& A, int l, int i, int ns, const cd* sh, MsRefl* refl,
+                          int W, int nsmax, MsStats* stats, Team<C>* team = nullptr) {
 #define HW(i_, j_) Hw[((i_) - ws) + ((j_) - ws) * WP]
     const int tid = ctx.tid(), nt = ctx.nthreads();
     const int na = i - l + 1;
     const int WP = W + 1;                                   // padded pitch of the LDS images
-    // scratch carve (after the areas hqr_eigvals_ms already uses: S, sh, refl, sinfo)
-    char* base = reinterpret_cast<char*>(refl + nsmax) + 64;   // past refl[nsmax] and the info word
-    const int TP = C::WS + 1;                               // pitch of a strip tile (one lane per column/row)
-    const int area = hqr_win_area_elems(W, C::WS);
-    cd* Hw = reinterpret_cast<cd*>(base);
-    cd* Tile = Hw + area;
-    MsRefl* logv = reinterpret_cast<MsRefl*>(Tile + area);
+    const WinLds L = win_lds(ctx, W, nsmax);
+    cd* Hw = L.Hw;
+    cd* Tile = L.Tile;
+    MsRefl* logv = L.logv;
     const int T = (na - 1) + 3 * (ns - 1);
     int t0 = 0;
+    if (team) team->g_batch = team->g;
     while (t0 < T) {
         // ---- window of this step: first row = row above the topmost active bulge
         int bh0 = t0 / 3;
@@ -370,7 +751,7 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
         const int wlen = we - ws;
         for (int idx = tid; idx < wlen * wlen; idx += nt) {
             const int r = idx % wlen, c = idx / wlen;
-            Hw[r + c * WP] = HH(ws + r, ws + c);
+            Hw[r + c * WP] = A.get(ws + r, ws + c);
         }
         ctx.sync();
         const long long c_b = KB_CLOCK();
@@ -440,146 +821,71 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
             }
             ctx.sync();
         }
-        // ---- (c) store the window back
         const long long c_c = KB_CLOCK();
+        WinGeom G;
+        G.l = l; G.i = i; G.na = na; G.ns = ns; G.t0 = t0; G.t1 = t1; G.nint = nint; G.ws = ws; G.we = we;
+        G.wlen = wlen; G.bmin = bmin; G.bmax = bmax;
+        if (team) {
+            // ---- publish the record (geometry + log) first: the helper's far tiles do not depend on
+            // the window image.  Slot reuse is safe: near_done >= g - 1 (waited for below at step g - 1)
+            // implies all_done >= g - 2.
+            Team<C>& tm = *team;
+            char* rec = tm.ring + (size_t)(tm.g % KB_TEAM_SLOTS) * tm.rec_bytes;
+#if defined(__HIP_DEVICE_COMPILE__)
+            __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rec, 0, tm.rec_bytes, 0x00020000);
+            if (tid < 3) {
+                kb_u4 h;
+                if (tid == 0) h = kb_u4{(unsigned)l, (unsigned)i, (unsigned)ns, (unsigned)na};
+                else if (tid == 1) h = kb_u4{(unsigned)t0, (unsigned)t1, (unsigned)ws, (unsigned)we};
+                else h = kb_u4{(unsigned)bmin, (unsigned)bmax, (unsigned)nint, tm.g};
+                __builtin_amdgcn_raw_buffer_store_b128(h, rr, tid * 16, 0, 16);
+            }
+            const int nq = (bmax - bmin + 1) * nint * 4;
+            const kb_u4* src = reinterpret_cast<const kb_u4*>(logv);
+            for (int idx = tid; idx < nq; idx += nt)
+                __builtin_amdgcn_raw_buffer_store_b128(src[idx], rr, (int)sizeof(TeamRec) + idx * 16, 0, 16);
+#else
+            (void)rec;
+#endif
+            team_signal(ctx, &tm.ctl->published, tm.g + 1);
+        }
+        // ---- (c) store the window back
         for (int idx = tid; idx < wlen * wlen; idx += nt) {
             const int r = idx % wlen, c = idx / wlen;
-            HH(ws + r, ws + c) = Hw[r + c * WP];
+            A.put(ws + r, ws + c, Hw[r + c * WP]);
         }
         ctx.sync();
         const long long c_d = KB_CLOCK();
-        // Replay the log bulge-major.  Two LDS tiles (the window image is free now):
-        // wavefronts 0 and 1.
-        // Two LDS tiles (the window image is free now).  With four wavefronts, two share a tile
-        // and split its bulges (and its rows for the copies); a bulge on one wavefront may
-        // follow a bulge of the other by two intervals on the same rows, hence one workgroup
-        // barrier per interval.  Every wavefront runs the same trip counts (barrier safety).
-        const int ntb = (ctx.nwaves() >= 2) ? 2 : 1;
-        // wavefronts per tile: 1, 2, 4 or 8 (each takes KB_MS_RG / nhalf bulges of every group)
-        const int nhalf = (ctx.nwaves() >= 8 * ntb) ? 8 : (ctx.nwaves() >= 4 * ntb) ? 4 : ((ctx.nwaves() >= 2 * ntb) ? 2 : 1);
-        const int slot = ctx.wave() % ntb, half = ctx.wave() / ntb;
-        const bool worker = ctx.wave() < ntb * nhalf;
-        // ---- (d) right strip: rows ws..we-1, columns we..i ; lanes = columns
-        // ---- (e) top strip:   rows l..ws-1,  columns ws..we-1 ; lanes = rows
-        const int nright = (we <= i) ? i - we + 1 : 0;
-        const int ntop = ws - l;
-        const int tiles_r = (nright + C::WS - 1) / C::WS, tiles_t = (ntop + C::WS - 1) / C::WS;
-        const int ntiles = tiles_r + tiles_t;
-        cd* Tl = (slot == 0) ? Hw : Tile;
-        const int lane = ctx.lane();
-        const int ngrp = (bmax - bmin) / KB_MS_RG + 1;
-        for (int round = 0; round * ntb < ntiles; ++round) {
-            const int tile = round * ntb + slot;
-            const bool right = tile < tiles_r;
-            const int q = (right ? we + tile * C::WS : l + (tile - tiles_r) * C::WS) + lane;
-            const bool live = worker && tile < ntiles && (right ? (q <= i) : (q < ws));
-            const double sg = right ? -1.0 : 1.0;                // right strip uses conj(t1), conj(t2), v2
-            const long long c_t0 = KB_CLOCK();
-            if (live) {
-                // this wavefront's share of the rows; eight global loads in flight per lane
-                int p = half;
-                for (; p + 7 * nhalf < wlen; p += 8 * nhalf) {
-                    cd v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = right ? HH(ws + p + u * nhalf, q) : HH(q, ws + p + u * nhalf);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) Tl[(p + u * nhalf) * TP + lane] = v[u];
-                }
-                for (; p < wlen; p += nhalf) Tl[p * TP + lane] = right ? HH(ws + p, q) : HH(q, ws + p);
+        int tiles_r, tiles_t;
+        win_tile_counts(G, C::WS, 0, 0, tiles_r, tiles_t);
+        if (!team) {
+            // ---- (d) right strip, (e) top strip: every tile
+            strip_tiles<0>(ctx, A, G, logv, Hw, Tile, 0, tiles_r, 0, tiles_t, 0, 0, stats, [](int) {});
+        } else {
+            Team<C>& tm = *team;
+#if !defined(__HIP_DEVICE_COMPILE__)
+            // host simulation: the helper's share of this record runs inline, in the order the protocol
+            // allows at the latest (before the chaser's own tiles of the same step would be too early
+            // for nothing: the regions are disjoint)
+            team_helper_record(ctx, tm, G, tm.g, L);
+#endif
+            // the nearest right / top tile of this step touch elements the helper wrote at step g - 1
+            // (its first far right tile) and earlier: wait for those; at the first step of a batch for
+            // everything before (top strips of the previous batch reach down to this window's columns)
+            bool ok = true;
+            if (tm.g > 0 && !tm.failed) {
+                if (tm.g == tm.g_batch) ok = team_wait(ctx, &tm.ctl->all_done, tm.g, tm.ctl, L.flag);
+                else ok = team_wait(ctx, &tm.ctl->near_done, tm.g, tm.ctl, L.flag);
             }
-            ctx.sync();
-            const long long c_t1 = KB_CLOCK();
-            auto replay = [&](auto nu_tag) {
-                constexpr int NU = decltype(nu_tag)::value;      // bulges handled by this wavefront per group
-                for (int g = 0; g < ngrp; ++g) {
-                    const int g0 = g * KB_MS_RG;
-                    int tb[NU], te[NU], pp[NU];
-                    cd carry[NU];
-                    int tt_lo = nint, tt_hi = 0;
-                    // interval range of the whole group (uniform over the workgroup)
-                    for (int u = 0; u < KB_MS_RG; ++u) {
-                        const int bb_ = bmin + g0 + u;
-                        int b0_ = 3 * bb_ - t0;
-                        if (b0_ < 0) b0_ = 0;
-                        int e0_ = 3 * bb_ + (na - 2) - t0 + 1;
-                        if (e0_ > nint) e0_ = nint;
-                        if (g0 + u <= bmax - bmin && e0_ > b0_) {
-                            tt_lo = b0_ < tt_lo ? b0_ : tt_lo;
-                            tt_hi = e0_ > tt_hi ? e0_ : tt_hi;
-                        }
-                    }
-                    // the bulges this wavefront replays: local u -> group index uo(u)
-                    const int u_base = half * NU;
-                    const int u_cnt = NU;
-    #pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        const int gu = u_base + u;
-                        const int bb_ = bmin + g0 + gu;
-                        int b0_ = 3 * bb_ - t0;
-                        if (b0_ < 0) b0_ = 0;
-                        int e0_ = 3 * bb_ + (na - 2) - t0 + 1;
-                        if (e0_ > nint) e0_ = nint;
-                        if (u >= u_cnt || g0 + gu > bmax - bmin) { b0_ = 0; e0_ = 0; }
-                        tb[u] = b0_; te[u] = e0_;
-                        pp[u] = (l + (t0 + b0_) - 3 * bb_) - ws;
-                        carry[u] = czero();
-                    }
-                    for (int tt = tt_lo; tt < tt_hi; ++tt) {
-                        if (live) {
-                            // LDS reads of the interval, then the arithmetic, then the writes
-                            cd nbv[NU], c1v[NU], c2v[NU], c3v[NU], outv[NU];
-#pragma unroll
-                            for (int u = 0; u < NU; ++u) {
-                                if (tt >= tb[u] && tt < te[u]) {
-                                    const int p = pp[u] + (tt - tb[u]);
-                                    const MsRefl* lg = logv + (g0 + u_base + u) * nint + tt;
-                                    if (tt == tb[u]) carry[u] = Tl[p * TP + lane];
-                                    nbv[u] = Tl[(p + 1) * TP + lane];
-                                    const cd t1 = lg->t1, t2 = lg->t2, v2 = lg->v2;
-                                    c1v[u] = mk(t1.x, sg * t1.y);
-                                    c2v[u] = mk(t2.x, sg * t2.y);
-                                    c3v[u] = mk(v2.x, -sg * v2.y);
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < NU; ++u) {
-                                if (tt >= tb[u] && tt < te[u]) {
-                                    const cd sum = c1v[u] * carry[u] + c2v[u] * nbv[u];
-                                    outv[u] = carry[u] - sum;
-                                    carry[u] = nbv[u] - sum * c3v[u];
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < NU; ++u) {
-                                if (tt >= tb[u] && tt < te[u]) {
-                                    const int p = pp[u] + (tt - tb[u]);
-                                    Tl[p * TP + lane] = outv[u];
-                                    if (tt == te[u] - 1) Tl[(p + 1) * TP + lane] = carry[u];
-                                }
-                            }
-                        }
-                        if (nhalf > 1) ctx.sync();
-                    }
-                }
-            };
-            if (nhalf == 8) replay(KbInt<KB_MS_RG / 8>{});
-            else if (nhalf == 4) replay(KbInt<KB_MS_RG / 4>{});
-            else if (nhalf == 2) replay(KbInt<KB_MS_RG / 2>{});
-            else replay(KbInt<KB_MS_RG>{});
-            ctx.sync();
-            const long long c_t2 = KB_CLOCK();
-            if (live) {
-                for (int p = half; p < wlen; p += nhalf) {
-                    if (right) HH(ws + p, q) = Tl[p * TP + lane];
-                    else HH(q, ws + p) = Tl[p * TP + lane];
-                }
+            if (!ok) tm.failed = 1;
+            // ---- (d)+(e) the near region: one merged tile (64-lane wavefronts) or one tile each
+            if (!tm.failed) {
+                if (C::WS >= 64)
+                    strip_tiles<1>(ctx, A, G, logv, Hw, Tile, 0, tiles_r > 0 ? 1 : 0, 0, tiles_t > 0 ? 1 : 0, 0, 0, stats, [](int) {});
+                else
+                    strip_tiles<0>(ctx, A, G, logv, Hw, Tile, 0, tiles_r > 0 ? 1 : 0, 0, tiles_t > 0 ? 1 : 0, 0, 0, stats, [](int) {});
             }
-            ctx.sync();
-            if (stats && tid == 0) {
-                const long long c_t3 = KB_CLOCK();
-                stats->cyc_tload += c_t1 - c_t0; stats->cyc_treplay += c_t2 - c_t1; stats->cyc_tstore += c_t3 - c_t2;
-                stats->ntiles++;
-            }
+            tm.g++;
         }
         ctx.sync();
         if (stats && tid == 0) {
@@ -591,12 +897,11 @@ KB_HD void chase_windowed(const C& ctx, cd* H, int ld, int l, int i, int ns, con
         t0 = t1;
     }
 #undef HW
-#undef HH
 }
 
 template <class C>
 KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, int nsmax,
-                          MsStats* stats = nullptr, int win_w = 0) {
+                          MsStats* stats = nullptr, int win_w = 0, Team<C>* team = nullptr) {
 #define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
     const double ulp = KB_ULP;
     const double smlnum = KB_SAFMIN * ((double)n / ulp);
@@ -607,9 +912,11 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
     MsRefl* refl = reinterpret_cast<MsRefl*>(sh + nsmax);
     int* sinfo = reinterpret_cast<int*>(refl + nsmax);
     int fail = 0;
+    bool bail = false;
     if (n == 1) {
         if (tid == 0) { w[0] = HH(0, 0); *info = 0; }
         ctx.sync();
+        if (team) team_signal(ctx, &team->ctl->done, 1u);
         return;
     }
     // (subdiagonals stay general complex numbers throughout: no realness is maintained)
@@ -696,14 +1003,29 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
                 if (stats && tid == 0) stats->cyc_shift += KB_CLOCK() - c_sh0;
                 // ---- pipelined chase of ns bulges, 3 rows apart
                 const int T = (na - 1) + 3 * (ns - 1);
-                if (win_w >= 3 * ns + 8)
-                    chase_windowed(ctx, H, ld, l, i, ns, sh, refl, win_w, nsmax, stats);
-                else
+                if (win_w >= 3 * ns + 8) {
+                    if (team) {
+                        chase_windowed(ctx, team->A, l, i, ns, sh, refl, win_w, nsmax, stats, team);
+#if defined(__HIP_DEVICE_COMPILE__)
+                        // the scan / shift / small-block code reads the band with plain loads: drop
+                        // whatever this CU's L1 still holds of it (the window was stored sc1)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+                        if (team->failed) { fail = 1; bail = true; }
+                    } else {
+                        chase_windowed(ctx, HPlain{H, ld}, l, i, ns, sh, refl, win_w, nsmax, stats);
+                    }
+                } else
                     chase_global(ctx, H, ld, l, i, ns, sh, refl);
                 if (stats && tid == 0) { stats->intervals += T; stats->batches++; }
+                if (bail) break;
             }
         }
         ctx.sync();
+        if (bail) {                 // team protocol failure: report the diagonal, flag the member
+            for (int r = tid; r <= i; r += nt) w[r] = HH(r, r);
+            break;
+        }
         if (done == 1) {
             if (tid == 0) w[i] = HH(i, i);
             i = l - 1;
@@ -720,6 +1042,7 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
     if (tid == 0) *info = fail;
     if (stats && tid == 0) stats->cyc_total += KB_CLOCK() - c_total0;
     ctx.sync();
+    if (team) team_signal(ctx, &team->ctl->done, 1u);
 #undef HH
 }
 

@@ -71,6 +71,9 @@ struct kbdm_ctx {
     int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
     int split_gen = 4;    // workgroups per item and matrix in k_gen
     int split_invit = 8;  // workgroups per item in k_invit
+    int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
+    int team_min_l = 192; // smallest l that gets a team
+    int team_max = 96;    // teams per launch: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
 };
 
@@ -105,6 +108,8 @@ struct kbdm_plan {
     cd* d_mu = nullptr;
     unsigned char* d_keep = nullptr;
     int* d_status = nullptr;
+    TeamCtl* d_team = nullptr;     // one control block per member
+    char* d_rings = nullptr;       // KB_TEAM_SLOTS records per member
     float stage_ms[KBDM_NSTAGES] = {0};
     bool timed = false;
 };
@@ -126,6 +131,7 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     return KBDM_OK;
 }
@@ -247,6 +253,8 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_keep, std::max<int64_t>(pl->total_lines, 1)));
     HIPCHK(hipMalloc(&pl->d_status, sizeof(int) * B));
     HIPCHK(hipMalloc(&pl->d_iwork, sizeof(int) * 4 * std::max(B, 1)));
+    HIPCHK(hipMalloc(&pl->d_team, sizeof(TeamCtl) * std::max(B, 1)));
+    HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS * team_rec_bytes(pl->ctx->ns_hqr, std::max(pl->ctx->win_hqr, 8))));
     HIPCHK(hipMalloc(&pl->d_rot, sizeof(Rot) * std::max<size_t>(pl->rot_elems, 1)));
     HIPCHK(hipMalloc(&pl->d_hdr, sizeof(RotBatch) * std::max<size_t>(pl->hdr_elems, 1)));
     if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
@@ -426,8 +434,23 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             HIPCHK(hipMalloc(&prof, sizeof(MsStats) * pl->B));
             HIPCHK(hipMemsetAsync(prof, 0, sizeof(MsStats) * pl->B, st));
         }
-        hipLaunchKernelGGL(k_hqr, dim3(ch.count), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof);
+        // Large members of the critical lane run as two-workgroup teams (k_hqr_team); the remaining
+        // members of the chunk run solo on the side stream (after k_gen(Qh)), concurrently.
+        int nteam = 0;
+        if (ctx->team_hqr && ch.lane == 0 && win > 0 && ln.stream2 != ln.stream) {
+            while (nteam < ch.count && nteam < ctx->team_max && pl->items[pl->perm[ch.first + nteam]].l >= ctx->team_min_l) ++nteam;
+        }
+        if (nteam > 0) {
+            HIPCHK(hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * pl->B, st));
+            hipLaunchKernelGGL(k_hqr_team, dim3(2 * nteam), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
+                               pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, pl->d_team, pl->d_rings, prof);
+        }
+        if (ch.count > nteam) {
+            hipStream_t ss = nteam > 0 ? ln.stream2 : st;
+            hipLaunchKernelGGL(k_hqr, dim3(ch.count - nteam), dim3(ctx->nt_hqr), sm, ss, pl->d_items, perm + nteam,
+                               pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof);
+            if (nteam > 0) HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));   // the join now covers Qh and the solo members
+        }
         if (do_prof) {   // diagnostic build path only: synchronous dump of the largest item's counters
             std::vector<MsStats> h(pl->B);
             HIPCHK(hipStreamSynchronize(st));
@@ -446,6 +469,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         int nw = std::min(ctx->nt_invit / 64, (LDS_MAX - 64 - KB_RED_BYTES) / per);
         if (nw < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
         const int sm = KB_RED_BYTES + nw * per;
+        HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // eigenvalues of the solo members (side stream) and Qh
         hipLaunchKernelGGL(k_invit, dim3(ch.count, ctx->split_invit), dim3(ctx->nt_invit), sm, st, pl->d_items, perm,
                            pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm);
         HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // Qh ready before k_gemm<3>
@@ -553,6 +577,9 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     if (c->win_hqr > 0 && c->win_hqr < 3 * c->ns_hqr + 8) c->win_hqr = 3 * c->ns_hqr + 8;
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
+    c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
+    c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
+    c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
     if (c->nt_hqr > 512) c->nt_hqr = 512;
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
     int r = set_lds_attr();
@@ -594,6 +621,7 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
     hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork); hipFree(pl->d_rot); hipFree(pl->d_hdr);
+    hipFree(pl->d_team); hipFree(pl->d_rings);
     for (auto& ch : pl->chunks)
         for (auto& e : ch.ev) hipEventDestroy(e);
     delete pl;

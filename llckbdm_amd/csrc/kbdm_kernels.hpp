@@ -528,6 +528,35 @@ __global__ void __launch_bounds__(512) k_hqr(const KbItem* __restrict__ items, c
     if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
 }
 
+// Team variant for large members: workgroup 2t is the chase workgroup of member t, workgroup 2t + 1
+// its helper on another CU (far strip tiles).  Team-major numbering: a team's two workgroups are
+// dispatched together.  The host launches at most as many teams as fit the chip at one workgroup per
+// CU, so every workgroup of the launch is resident; all waits are bounded (abort flag + status bit).
+__global__ void __launch_bounds__(512) k_hqr_team(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                    cd* arena, cd* mu_out, int* status, int smem_bytes,
+                                                    int nsmax, int win_w, TeamCtl* ctl, char* rings, MsStats* prof) {
+    const int team = blockIdx.x >> 1, role = blockIdx.x & 1;
+    const int item = perm[team];
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    cd* Hc = arena + it.off[KB_BUF_H];
+    Team<DevCtx> tm;
+    tm.ctl = ctl + item;
+    tm.rec_bytes = team_rec_bytes(nsmax, win_w);
+    tm.ring = rings + (size_t)item * KB_TEAM_SLOTS * tm.rec_bytes;
+    tm.g = 0; tm.g_batch = 0; tm.failed = 0;
+    tm.A = HSc1::make(Hc, it.l, it.l);
+    tm.W = win_w; tm.nsmax = nsmax;
+    if (role == 0) {
+        cd* mu = mu_out + it.line_off;
+        __shared__ int info;
+        hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, prof ? prof + item : nullptr, win_w, &tm);
+        if (threadIdx.x == 0 && info != 0) atomicOr(&status[item], KB_STAT_EIG_NOCONV);
+    } else {
+        team_helper_main(ctx, tm);
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_invit(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                  cd* arena, double* varena, const cd* mu_out, int* status,
                                                  int smem_bytes) {

@@ -148,6 +148,38 @@ int hs_eigvals_ms(const double* W_in, int n, int nsmax, int win_w, double* mu_ou
     return info;
 }
 
+// Same, through the workgroup-TEAM code path: the helper workgroup's share of every record is run
+// inline (sequentially) by the one host thread, so tile partition, record layout and bookkeeping of
+// the protocol are exercised; the waits themselves are device-only.
+int hs_eigvals_team(const double* W_in, int n, int nsmax, int win_w, double* mu_out, long long* stats_out) {
+    std::vector<cd> W(n * n), Hc(n * n), th(n);
+    memcpy(W.data(), W_in, sizeof(cd) * n * n);
+    std::vector<char> arena;
+    if (nsmax > KB_MS_NSMAX) nsmax = KB_MS_NSMAX;
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_win_scratch_bytes(nsmax, win_w > 0 ? win_w : 8, 1));
+    gehd2(ctx, n, W.data(), n, th.data());
+    hess_copy(ctx, n, W.data(), n, Hc.data(), n);
+    int info = 0;
+    MsStats st;
+    memset(&st, 0, sizeof(st));
+    TeamCtl ctl;
+    memset(&ctl, 0, sizeof(ctl));
+    Team<HostCtx> tm;
+    tm.ctl = &ctl;
+    tm.rec_bytes = team_rec_bytes(nsmax, win_w);
+    std::vector<char> ring((size_t)KB_TEAM_SLOTS * tm.rec_bytes);
+    tm.ring = ring.data();
+    tm.g = 0; tm.g_batch = 0; tm.failed = 0;
+    tm.A = HSc1::make(Hc.data(), n, n);
+    tm.W = win_w; tm.nsmax = nsmax;
+    hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st, win_w, &tm);
+    if (stats_out) {
+        stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps;
+        stats_out[4] = ctl.published; stats_out[5] = ctl.all_done; stats_out[6] = ctl.done; stats_out[7] = ctl.near_done;
+    }
+    return info;
+}
+
 // Full single-member pipeline (reference kbdm.py:19-92) with the host context.
 //   signal: N complex; lines: l x 4 row-major (A, T2, F, PH); sv: m; mu: l complex
 int hs_kbdm(const double* signal, int N, int m, int l, int p, double q, double dwell,
