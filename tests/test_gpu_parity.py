@@ -84,6 +84,24 @@ def test_eig_stage(eng):
         assert np.all(np.abs(P).max(axis=0) > 0)
 
 
+def test_eig_team_and_solo_paths_agree_bitwise(monkeypatch):
+    """k_hqr_team (chase workgroup + helper workgroup on two CUs, hand-off through HBM) applies
+    exactly the arithmetic of the one-workgroup k_hqr, element by element: any stale or torn hand-off
+    shows up as a difference.  Several members at once, so that teams run under uneven load."""
+    from llckbdm_amd.engine import Engine
+    rng = np.random.default_rng(11)
+    mats = [rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) for n in (400, 333, 256, 200, 192, 150)]
+    monkeypatch.setenv("KBDM_TEAM_HQR", "0")
+    solo, st0 = Engine(0).eig(mats)
+    monkeypatch.setenv("KBDM_TEAM_HQR", "1")
+    team, st1 = Engine(0).eig(mats)
+    assert not (st0 & 3).any() and not (st1 & 3).any()
+    for W, (mu0, _), (mu1, _) in zip(mats, solo, team):
+        assert np.array_equal(mu0, mu1)
+        ref = np.linalg.eigvals(W)
+        assert np.abs(mu1[:, None] - ref[None, :]).min(axis=1).max() < 1e-11 * np.abs(W).sum(axis=1).max()
+
+
 # ---------------------------------------------------------------- a1-a12: whole member
 WELL_POSED = ["c1", "m300", "m150", "m100", "m101", "m102", "m180l30", "m64p2", "n3m128", "n3m256", "n6m256", "n3m512"]
 

@@ -68,6 +68,24 @@ def test_eig_random(hs):
         assert np.abs(mu[:, None] - ref[None, :]).min(axis=1).max() < 1e-11
 
 
+def test_team_protocol_bookkeeping_matches_solo(hs):
+    """The two-workgroup TEAM variant of the QR iteration (chase workgroup + helper workgroup,
+    kb_hqr_ms.hpp) with the helper's share run inline: same tile partition, record ring and counters as
+    on the device, and bit-identical eigenvalues to the one-workgroup path."""
+    rng = np.random.default_rng(5)
+    for n, ns, win in ((13, 8, 32), (70, 8, 56), (120, 8, 56), (90, 4, 24)):
+        W = np.asfortranarray(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        mu_s, mu_t = np.zeros(n, complex), np.zeros(n, complex)
+        st_s, st_t = np.zeros(8, np.int64), np.zeros(8, np.int64)
+        assert hs.hs_eigvals_ms(W.ctypes.data_as(P), n, ns, win, mu_s.ctypes.data_as(P), st_s.ctypes.data_as(P)) == 0
+        assert hs.hs_eigvals_team(W.ctypes.data_as(P), n, ns, win, mu_t.ctypes.data_as(P), st_t.ctypes.data_as(P)) == 0
+        assert np.array_equal(mu_s, mu_t)
+        ref = np.linalg.eigvals(W)
+        assert np.abs(mu_t[:, None] - ref[None, :]).min(axis=1).max() < 1e-11
+        published, all_done, done, near_done = (int(x) for x in st_t[4:8])
+        assert published == st_t[3] > 0 and all_done == published and near_done == published and done == 1
+
+
 @pytest.mark.parametrize("name", ["m100", "m64p2", "m180l30", "m10q", "n3m128"])
 def test_pipeline_matches_reference_golden(hs, golden, name):
     m, l, p = (int(x) for x in golden[f"{name}__meta"])
