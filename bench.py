@@ -191,8 +191,12 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/), if any
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_final_pmc_traffic.json")))["kernels"]
-            traffic = pmc.get(dom, pmc.get(dom.split("(")[0], {})).get("hbm_bytes_per_launch")
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_team_pmc_traffic.json")))["kernels"]
+            # lane 0 runs the QR iteration as k_hqr_team; k_gen is templated on the register chunk count
+            for key in (dom + "_team", dom, dom.split("(")[0], dom.split("(")[0] + "<8>"):
+                if key in pmc:
+                    traffic = pmc[key].get("hbm_bytes_per_launch")
+                    break
         except Exception:
             traffic = None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
