@@ -35,26 +35,47 @@ struct DevCtx {
     __device__ __forceinline__ char* scratch() const { return smem + KB_RED_BYTES; }
     __device__ __forceinline__ int scratch_bytes() const { return smem_bytes - KB_RED_BYTES; }
 
+    // Wavefront reductions without the LDS crossbar: four DPP butterfly stages inside each row of 16
+    // lanes (quad_perm 1, quad_perm 2, row_half_mirror, row_mirror), then the four row results through
+    // v_readlane.  Every stage combines the same two partial values in every lane (commutative ops), so
+    // all 64 lanes end with identical bits.  All lanes of the wavefront must be active.
+    template <int CTRL>
+    __device__ static __forceinline__ double dpp_f64(double v) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ static __forceinline__ double lane_f64(double v, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                                __builtin_amdgcn_readlane(__double2loint(v), l));
+    }
     __device__ __forceinline__ double wave_sum(double v) const {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
+        v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+        v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+        v += dpp_f64<0x141>(v);     // row_half_mirror
+        v += dpp_f64<0x140>(v);     // row_mirror
+        return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
     }
     __device__ __forceinline__ cd wave_sum(cd v) const {
         return mk(wave_sum(v.x), wave_sum(v.y));
     }
     __device__ __forceinline__ double wave_max(double v) const {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-        return v;
+        v = fmax(v, dpp_f64<0xB1>(v));
+        v = fmax(v, dpp_f64<0x4E>(v));
+        v = fmax(v, dpp_f64<0x141>(v));
+        v = fmax(v, dpp_f64<0x140>(v));
+        return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
     }
     __device__ __forceinline__ int wave_max(int v) const {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            int t = __shfl_xor(v, o, 64);
-            v = t > v ? t : v;
-        }
-        return v;
+        int t;
+        t = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); v = t > v ? t : v;
+        t = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); v = t > v ? t : v;
+        t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); v = t > v ? t : v;
+        t = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true); v = t > v ? t : v;
+        const int a0 = __builtin_amdgcn_readlane(v, 0), a1 = __builtin_amdgcn_readlane(v, 16);
+        const int a2 = __builtin_amdgcn_readlane(v, 32), a3 = __builtin_amdgcn_readlane(v, 48);
+        const int m0 = a0 > a1 ? a0 : a1, m1 = a2 > a3 ? a2 : a3;
+        return m0 > m1 ? m0 : m1;
     }
     // Block reductions: every thread must call; every thread receives the same bits
     // (fixed summation order), so data-dependent branches taken on the result are uniform.
