@@ -149,15 +149,32 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
             yv = ctx.block_sum(part);
         }
         // ---- 5. z = tau (A0[k+1:, k+1:]^H v - V w3 - Z w1 - v yv), columns k+1..N-1
-        for (int c = k + 1 + ctx.wave(); c < N; c += ctx.nwaves()) {
-            cd g = czero(), g1 = czero();
+        // two columns per wavefront at a time, two row chunks each: four loads in flight per lane
+        for (int c0 = k + 1 + 2 * ctx.wave(); c0 < N; c0 += 2 * ctx.nwaves()) {
+            const int c1 = (c0 + 1 < N) ? c0 + 1 : c0;
+            cd g0 = czero(), g1 = czero(), h0 = czero(), h1 = czero();
             int r = k + 1 + lane;
-            for (; r + C::WS < N; r += 2 * C::WS) { cfmac(g, W_(r, c), ub[r]); cfmac(g1, W_(r + C::WS, c), ub[r + C::WS]); }
-            for (; r < N; r += C::WS) cfmac(g, W_(r, c), ub[r]);
-            cd corr = czero();
-            for (int t = lane; t < j; t += C::WS) corr = corr + hess_vt(W, ld, p0, c, t) * w3[t] + Z_(c, t) * w1[t];
-            g = ctx.wave_sum((g + g1) - corr);
-            if (lane == 0) Z_(c, j) = tau * (g - ub[c] * yv);
+            for (; r + C::WS < N; r += 2 * C::WS) {
+                const cd a00 = W_(r, c0), a01 = W_(r, c1), a10 = W_(r + C::WS, c0), a11 = W_(r + C::WS, c1);
+                const cd v0 = ub[r], v1 = ub[r + C::WS];
+                cfmac(g0, a00, v0); cfmac(g1, a01, v0); cfmac(h0, a10, v1); cfmac(h1, a11, v1);
+            }
+            for (; r < N; r += C::WS) {
+                const cd a00 = W_(r, c0), a01 = W_(r, c1);
+                const cd v0 = ub[r];
+                cfmac(g0, a00, v0); cfmac(g1, a01, v0);
+            }
+            cd corr0 = czero(), corr1 = czero();
+            for (int t = lane; t < j; t += C::WS) {
+                corr0 = corr0 + hess_vt(W, ld, p0, c0, t) * w3[t] + Z_(c0, t) * w1[t];
+                corr1 = corr1 + hess_vt(W, ld, p0, c1, t) * w3[t] + Z_(c1, t) * w1[t];
+            }
+            const cd s0 = ctx.wave_sum((g0 + h0) - corr0);
+            const cd s1 = ctx.wave_sum((g1 + h1) - corr1);
+            if (lane == 0) {
+                Z_(c0, j) = tau * (s0 - ub[c0] * yv);
+                if (c0 + 1 < N) Z_(c0 + 1, j) = tau * (s1 - ub[c0 + 1] * yv);
+            }
         }
         for (int c = tid; c <= k; c += nt) Z_(c, j) = czero();
         ctx.sync();

@@ -71,6 +71,7 @@ struct kbdm_ctx {
     int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
     int split_gen = 4;    // workgroups per item and matrix in k_gen
     int split_invit = 8;  // workgroups per item in k_invit
+    int stream_replay = 1; // rotation replay through registers (k_bdsqr_stream) instead of LDS-resident rows
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
     int team_max = 96;    // teams per launch: 2 workgroups each, one workgroup per CU, all resident
@@ -372,6 +373,12 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             buckets.push_back(Bucket{pos, end - pos, groups, sm});
             pos = end;
         }
+        if (ctx->stream_replay) {
+            // streaming replay: no LDS, one launch for the whole chunk
+            hipLaunchKernelGGL(k_bdsqr_stream, dim3((2 * ch.mmax + 63) / 64, ch.count, 2), dim3(64), 0, st, pl->d_items,
+                               perm, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, flag_mode ? 1 : 0);
+            buckets.clear();
+        }
         for (int b = (int)buckets.size() - 1; b >= 0; --b) {
             const Bucket& bk = buckets[b];
             hipLaunchKernelGGL(k_bdsqr_apply, dim3(bk.groups, bk.cnt, 2), dim3(64), bk.sm, st, pl->d_items,
@@ -578,6 +585,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
     c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
+    c->stream_replay = env_int("KBDM_STREAM_REPLAY", c->stream_replay);
     c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
     c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
     if (c->nt_hqr > 512) c->nt_hqr = 512;

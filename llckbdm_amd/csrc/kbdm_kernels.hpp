@@ -283,6 +283,38 @@ __global__ void __launch_bounds__(64) k_bdsqr_apply(const KbItem* __restrict__ i
     bdsqr_apply_rows(ctx, m, X, m, row0, nrows, (int)blockIdx.z, hdr, rot, nb);
 }
 
+// Part 2, streaming form (default): one lane per real component of a row, rows pass through a register
+// window (bdsqr_stream_lane), no LDS, so many wavefronts share a SIMD.  grid (ceil(2 m / 64), members, 2).
+__global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                      cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
+                                                      int* iwork, int wait_flag) {
+    const int item = perm[blockIdx.y];
+    const KbItem it = items[item];
+    const int m = it.m;
+    if ((int)blockIdx.x * 64 >= 2 * m) return;
+    const int vl = blockIdx.x * 64 + threadIdx.x;
+    if (wait_flag) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&iwork[4 * item + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+                   spins < (1u << 26)) {
+                __builtin_amdgcn_s_sleep(32);
+                ++spins;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    // the log pointers are laundered so that no load of the log can be scheduled above the wait
+    const RotBatch* hdr = hdr_all + it.hdr_off;
+    const Rot* rot = rot_all + it.rot_off;
+    asm volatile("" : "+s"(hdr), "+s"(rot)::"memory");
+    const int nb = __hip_atomic_load(&iwork[4 * item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double* X = reinterpret_cast<double*>(arena + it.off[blockIdx.z == 0 ? KB_BUF_Q : KB_BUF_P]);
+    bdsqr_stream_lane<8>(X + vl, vl < 2 * m, (size_t)m, (int)blockIdx.z, hdr, rot, 0, nb);
+}
+
 // Part 3: sign fix, descending sort, permuted copy into L (A buffer) and R, Dsqi, outputs.
 __global__ void __launch_bounds__(1024) k_bdsqr_sort(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                       cd* arena, double* varena, double* sv_out, int* status,
