@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ ite
     const DevCtx ctx = make_ctx(smem_bytes);
     double* dv = varena + it.voff;
     bdsqr_gen(ctx, it.m, dv + KB_V_D * it.vstride, dv + KB_V_E * it.vstride, hdr_all + it.hdr_off,
-              rot_all + it.rot_off, &iwork[4 * item], &iwork[4 * item + 1]);
+              rot_all + it.rot_off, &iwork[4 * item], &iwork[4 * item + 1], &iwork[4 * item + 2]);
     // publish: every lane's stores drained, then release, then the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -293,26 +293,42 @@ __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ 
     const int m = it.m;
     if ((int)blockIdx.x * 64 >= 2 * m) return;
     const int vl = blockIdx.x * 64 + threadIdx.x;
-    if (wait_flag) {
-        if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(&iwork[4 * item + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-                   spins < (1u << 26)) {
-                __builtin_amdgcn_s_sleep(32);
-                ++spins;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-    }
-    // the log pointers are laundered so that no load of the log can be scheduled above the wait
-    const RotBatch* hdr = hdr_all + it.hdr_off;
-    const Rot* rot = rot_all + it.rot_off;
-    asm volatile("" : "+s"(hdr), "+s"(rot)::"memory");
-    const int nb = __hip_atomic_load(&iwork[4 * item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool live = vl < 2 * m;
     double* X = reinterpret_cast<double*>(arena + it.off[blockIdx.z == 0 ? KB_BUF_Q : KB_BUF_P]);
-    bdsqr_stream_lane<8>(X + vl, vl < 2 * m, (size_t)m, (int)blockIdx.z, hdr, rot, 0, nb);
+    const RotBatch* hdr0 = hdr_all + it.hdr_off;
+    const Rot* rot0 = rot_all + it.rot_off;
+    if (!wait_flag) {           // stream dependency on the generator: the whole log is there
+        const int nb = iwork[4 * item];
+        bdsqr_stream_lane<8>(X + vl, live, (size_t)m, (int)blockIdx.z, hdr0, rot0, 0, nb);
+        return;
+    }
+    // Follow the generator: replay whatever whole groups of eight sweeps it has published, sleep when
+    // caught up, finish with the rest once it is done.  (One wavefront per workgroup: every lane polls
+    // the same words; the values are made uniform.)  After every successful poll: agent acquire for the
+    // vector L1, s_dcache_inv for the scalar cache the log is read through, and the log pointers are
+    // laundered so that no load of the log is reused or hoisted across the wait.
+    int b = 0;
+    unsigned spins = 0;
+    for (;;) {
+        const int done = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&iwork[4 * item + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        int avail = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&iwork[4 * item + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (!done && avail - b < 8) {
+            if (++spins > (1u << 26)) return;          // generator lost: leave (status is set by k_bdsqr_sort's checks)
+            __builtin_amdgcn_s_sleep(32);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        const RotBatch* hdr = hdr0;
+        const Rot* rot = rot0;
+        asm volatile("" : "+s"(hdr), "+s"(rot)::"memory");
+        if (done) avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&iwork[4 * item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        bdsqr_stream_lane<8>(X + vl, live, (size_t)m, (int)blockIdx.z, hdr, rot, b, avail);
+        b = avail;
+        if (done) break;
+    }
 }
 
 // Part 3: sign fix, descending sort, permuted copy into L (A buffer) and R, Dsqi, outputs.
