@@ -71,7 +71,6 @@ struct kbdm_ctx {
     int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
     int split_gen = 4;    // workgroups per item and matrix in k_gen
     int split_invit = 8;  // workgroups per item in k_invit
-    int stream_replay = 1; // rotation replay through registers (k_bdsqr_stream) instead of LDS-resident rows
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
     int team_max = 96;    // teams per launch: 2 workgroups each, one workgroup per CU, all resident
@@ -127,7 +126,6 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svd_fac), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_gen), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_apply), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_sort), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
@@ -348,42 +346,10 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { r = tm->mark(); if (r) return r; }      // k_bdsqr_gen slot (overlapped)
     }
     {
-        // Rotation replay, launched per size bucket, SMALLEST members first (their logs are
-        // complete first): rows per wavefront = as many as fit the LDS granted to the bucket
-        // (at most 32: two lanes per row), so that small members do not inherit the LDS
-        // footprint - and the one-workgroup-per-CU occupancy - of the largest.
-        struct Bucket { int pos, cnt, groups, sm; };
-        std::vector<Bucket> buckets;
-        int pos = 0;
-        while (pos < ch.count) {
-            const int mhi = pl->items[pl->perm[ch.first + pos]].m;
-            int R = (LDS_MAX - 64 - KB_RED_BYTES) / ((mhi + 1) * (int)sizeof(cd));
-            if (R < 1) return fail(KBDM_E_NOMEM, "m too large for the rotation replay");
-            if (R > 32) R = 32;
-            const int sm = KB_RED_BYTES + R * (mhi + 1) * (int)sizeof(cd);
-            const int mlo = (R == 32) ? std::max(1, mhi - 48) : mhi - 16;     // bucket: members down to mlo
-            int end = pos, groups = 1;
-            while (end < ch.count && pl->items[pl->perm[ch.first + end]].m >= mlo) {
-                const int mi = pl->items[pl->perm[ch.first + end]].m;
-                int Ri = (sm - KB_RED_BYTES) / ((mi + 1) * (int)sizeof(cd));
-                if (Ri > 32) Ri = 32;
-                groups = std::max(groups, (mi + Ri - 1) / Ri);
-                ++end;
-            }
-            buckets.push_back(Bucket{pos, end - pos, groups, sm});
-            pos = end;
-        }
-        if (ctx->stream_replay) {
-            // streaming replay: no LDS, one launch for the whole chunk
-            hipLaunchKernelGGL(k_bdsqr_stream, dim3((2 * ch.mmax + 63) / 64, ch.count, 2), dim3(64), 0, st, pl->d_items,
-                               perm, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, flag_mode ? 1 : 0);
-            buckets.clear();
-        }
-        for (int b = (int)buckets.size() - 1; b >= 0; --b) {
-            const Bucket& bk = buckets[b];
-            hipLaunchKernelGGL(k_bdsqr_apply, dim3(bk.groups, bk.cnt, 2), dim3(64), bk.sm, st, pl->d_items,
-                               perm + bk.pos, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, bk.sm, flag_mode ? 1 : 0);
-        }
+        // Rotation replay (streaming, no LDS): one launch for the whole chunk; with the in-kernel hand-off
+        // its wavefronts follow the generators set by set.
+        hipLaunchKernelGGL(k_bdsqr_stream, dim3((2 * ch.mmax + 63) / 64, ch.count, 2), dim3(64), 0, st, pl->d_items,
+                           perm, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, flag_mode ? 1 : 0);
         if (flag_mode) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
@@ -585,7 +551,6 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
     c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
-    c->stream_replay = env_int("KBDM_STREAM_REPLAY", c->stream_replay);
     c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
     c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
     if (c->nt_hqr > 512) c->nt_hqr = 512;

@@ -245,45 +245,8 @@ __global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ ite
     }
 }
 
-// Part 2: the logged rotations are applied to the rows of Q (blockIdx.z = 0) and P (= 1).
-// One wavefront owns a group of rows, staged in LDS for the whole replay.  If `wait_flag`, the
-// kernel was launched without a stream dependency on k_bdsqr_gen and waits for the item's DONE
-// word itself (relaxed poll, one agent-scope acquire).
-__global__ void __launch_bounds__(64) k_bdsqr_apply(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                     cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
-                                                     int* iwork, int smem_bytes, int wait_flag) {
-    const int item = perm[blockIdx.y];
-    const KbItem it = items[item];
-    const DevCtx ctx = make_ctx(smem_bytes);
-    const int m = it.m;
-    int R = ctx.scratch_bytes() / ((m + 1) * (int)sizeof(cd));
-    if (R > 32) R = 32;
-    const int row0 = blockIdx.x * R;
-    if (row0 >= m) return;
-    const int nrows = (row0 + R <= m) ? R : m - row0;
-    if (wait_flag) {
-        if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(&iwork[4 * item + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-                   spins < (1u << 26)) {
-                __builtin_amdgcn_s_sleep(32);
-                ++spins;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-    }
-    // the log pointers are laundered so that no load of the log can be scheduled above the wait
-    const RotBatch* hdr = hdr_all + it.hdr_off;
-    const Rot* rot = rot_all + it.rot_off;
-    asm volatile("" : "+s"(hdr), "+s"(rot)::"memory");
-    const int nb = __hip_atomic_load(&iwork[4 * item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cd* X = arena + it.off[blockIdx.z == 0 ? KB_BUF_Q : KB_BUF_P];
-    bdsqr_apply_rows(ctx, m, X, m, row0, nrows, (int)blockIdx.z, hdr, rot, nb);
-}
-
-// Part 2, streaming form (default): one lane per real component of a row, rows pass through a register
+// Part 2: the logged rotations are applied to the rows of Q (blockIdx.z = 0) and P (= 1): one lane per
+// real component of a row, rows pass through a register
 // window (bdsqr_stream_lane), no LDS, so many wavefronts share a SIMD.  grid (ceil(2 m / 64), members, 2).
 __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                       cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
@@ -299,11 +262,11 @@ __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ 
     const Rot* rot0 = rot_all + it.rot_off;
     if (!wait_flag) {           // stream dependency on the generator: the whole log is there
         const int nb = iwork[4 * item];
-        bdsqr_stream_lane<8>(X + vl, live, (size_t)m, (int)blockIdx.z, hdr0, rot0, 0, nb);
+        bdsqr_stream_lane(X + vl, live, (size_t)m, (int)blockIdx.z, hdr0, rot0, 0, nb);
         return;
     }
-    // Follow the generator: replay whatever whole groups of eight sweeps it has published, sleep when
-    // caught up, finish with the rest once it is done.  (One wavefront per workgroup: every lane polls
+    // Follow the generator: replay whatever sets of sweeps it has published, sleep when caught up,
+    // finish with the rest once it is done.  (One wavefront per workgroup: every lane polls
     // the same words; the values are made uniform.)  After every successful poll: agent acquire for the
     // vector L1, s_dcache_inv for the scalar cache the log is read through, and the log pointers are
     // laundered so that no load of the log is reused or hoisted across the wait.
@@ -314,7 +277,7 @@ __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ 
             __hip_atomic_load(&iwork[4 * item + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         int avail = __builtin_amdgcn_readfirstlane(
             __hip_atomic_load(&iwork[4 * item + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (!done && avail - b < 8) {
+        if (!done && avail <= b) {
             if (++spins > (1u << 26)) return;          // generator lost: leave (status is set by k_bdsqr_sort's checks)
             __builtin_amdgcn_s_sleep(32);
             continue;
@@ -325,7 +288,7 @@ __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ 
         const Rot* rot = rot0;
         asm volatile("" : "+s"(hdr), "+s"(rot)::"memory");
         if (done) avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&iwork[4 * item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        bdsqr_stream_lane<8>(X + vl, live, (size_t)m, (int)blockIdx.z, hdr, rot, b, avail);
+        bdsqr_stream_lane(X + vl, live, (size_t)m, (int)blockIdx.z, hdr, rot, b, avail);
         b = avail;
         if (done) break;
     }

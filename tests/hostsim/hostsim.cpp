@@ -55,8 +55,7 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
     std::vector<double> d(m), e(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) +
-                                      bdsqr_apply_scratch_bytes(m, m) + 4 * m);
+    HostCtx ctx = make_ctx(arena, bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) + 4 * m);
     hs_bidiag_blocked(ctx, m, A.data(), d.data(), e.data(), tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
@@ -64,15 +63,15 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
     std::vector<RotBatch> hdr(bdsqr_log_batches_cap(m));
     std::vector<Rot> rot(bdsqr_log_steps_cap(m));
     bdsqr_gen(ctx, m, d.data(), e.data(), hdr.data(), rot.data(), &nb, &info);
-    bdsqr_apply_rows(ctx, m, Q.data(), m, 0, m, 0, hdr.data(), rot.data(), nb);
-    bdsqr_apply_rows(ctx, m, P.data(), m, 0, m, 1, hdr.data(), rot.data(), nb);
+    bdsqr_apply_ref(m, Q.data(), m, 0, hdr.data(), rot.data(), nb);     // reference replay, sweep by sweep
+    bdsqr_apply_ref(m, P.data(), m, 1, hdr.data(), rot.data(), nb);
     sort_sv(ctx, m, d.data(), Q.data(), m, P.data(), m, s_out, reinterpret_cast<cd*>(L_out), m,
             reinterpret_cast<cd*>(R_out), m);
     return info;
 }
 
 // Same factorisation with the STREAMING replay of the rotation log (bdsqr_stream_lane: register
-// window, wavefront over groups of S sweeps) instead of the LDS-resident one; `split` > 1 also exercises
+// window, the sweeps of a set as a wavefront) instead of the reference replay; `split` > 1 also exercises
 // resuming the replay at a batch boundary (what the device does while the generator is still running).
 int hs_svd_stream(const double* A_in, int m, double* L_out, double* s_out, double* R_out, int split) {
     std::vector<cd> A(m * m), Q(m * m), P(m * m), UR(m * m), tq(m), tp(m);
@@ -93,7 +92,7 @@ int hs_svd_stream(const double* A_in, int m, double* L_out, double* s_out, doubl
         for (int vl = 0; vl < 2 * m; ++vl)
             for (int part = 0; part < split; ++part) {
                 const int b0 = (int)((long long)nb * part / split), b1 = (int)((long long)nb * (part + 1) / split);
-                bdsqr_stream_lane<8>(X + vl, true, (size_t)m, which, hdr.data(), rot.data(), b0, b1);
+                bdsqr_stream_lane(X + vl, true, (size_t)m, which, hdr.data(), rot.data(), b0, b1);
             }
     }
     sort_sv(ctx, m, d.data(), Q.data(), m, P.data(), m, s_out, reinterpret_cast<cd*>(L_out), m,
