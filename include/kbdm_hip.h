@@ -112,6 +112,22 @@ int kbdm_svd_batch(kbdm_ctx* ctx, const double* A, int B, const int32_t* m, doub
 int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, double* mu, double* P,
                    int32_t* status);
 
+/* ---- rows next to the hot path (consumers of the line lists) -------------------------------- */
+
+/* Frequency-domain RMSE of `ncand` candidate line lists against one signal: replaces
+ * llckbdm/metrics.py:7-17 (calculate_freq_domain_rmse) as called per candidate by
+ * llckbdm/min_rmse_kbdm.py:33-38.  data: N complex128; lines: packed rows (A, T2, F, PH) of all
+ * candidates; cand_off[ncand+1]: row ranges (an empty range gives +inf, as min_rmse_kbdm.py:36-37);
+ * rmse_out[ncand]. */
+int kbdm_rmse_batch(kbdm_ctx* ctx, const double* data, int N, double dwell, const double* lines,
+                    const int64_t* cand_off, int ncand, double* rmse_out);
+
+/* Silhouette coefficient of every sample, Euclidean metric: replaces
+ * sklearn.metrics.silhouette_samples as called by llckbdm/llckbdm.py:291.  X: n x dim float64
+ * row-major (dim <= 8); labels[n] (any integers; -1 is a class of its own, as in the reference);
+ * out[n].  Needs at least 2 classes and at most n - 1 (sklearn's precondition). */
+int kbdm_silhouette_samples(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* labels, double* out);
+
 #ifdef __cplusplus
 }
 #endif

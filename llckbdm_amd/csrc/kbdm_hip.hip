@@ -10,10 +10,12 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../include/kbdm_hip.h"
 #include "kbdm_kernels.hpp"
+#include "kbdm_next.hpp"
 
 using namespace kb;
 
@@ -855,6 +857,81 @@ int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, doub
     } while (0);
     hipFree(d_dense);
     kbdm_plan_destroy(pl);
+    return r;
+}
+
+// ---------------------------------------------------------------- rows next to the hot path
+int kbdm_rmse_batch(kbdm_ctx* ctx, const double* data, int N, double dwell, const double* lines,
+                    const int64_t* cand_off, int ncand, double* rmse_out) {
+    if (!ctx || !data || !cand_off || !rmse_out || N < 1 || ncand < 0) return fail(KBDM_E_INVALID, "bad rmse arguments");
+    if (ncand == 0) return KBDM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t nrows = cand_off[ncand];
+    if (nrows < 0 || (nrows > 0 && !lines)) return fail(KBDM_E_INVALID, "bad candidate offsets");
+    for (int c = 0; c < ncand; ++c)
+        if (cand_off[c + 1] < cand_off[c]) return fail(KBDM_E_INVALID, "candidate offsets must be non-decreasing");
+    cd *d_data = nullptr, *d_res = nullptr;
+    double *d_lines = nullptr, *d_out = nullptr;
+    long long* d_off = nullptr;
+    hipStream_t st = ctx->stream;
+    int r = KBDM_OK;
+    do {
+        if (hipMalloc(&d_data, sizeof(cd) * N) != hipSuccess || hipMalloc(&d_res, sizeof(cd) * (size_t)N * ncand) != hipSuccess ||
+            hipMalloc(&d_lines, sizeof(double) * 4 * std::max<int64_t>(nrows, 1)) != hipSuccess ||
+            hipMalloc(&d_off, sizeof(long long) * (ncand + 1)) != hipSuccess || hipMalloc(&d_out, sizeof(double) * ncand) != hipSuccess) {
+            r = fail(KBDM_E_NOMEM, "hipMalloc (rmse)");
+            break;
+        }
+        hipMemcpyAsync(d_data, data, sizeof(cd) * N, hipMemcpyHostToDevice, st);
+        if (nrows > 0) hipMemcpyAsync(d_lines, lines, sizeof(double) * 4 * nrows, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_off, cand_off, sizeof(long long) * (ncand + 1), hipMemcpyHostToDevice, st);
+        hipLaunchKernelGGL(k_rmse, dim3(ncand), dim3(256), 0, st, d_data, N, dwell, d_lines, d_off, d_res, d_out);
+        hipMemcpyAsync(rmse_out, d_out, sizeof(double) * ncand, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "rmse kernel failed"); break; }
+        for (int c = 0; c < ncand; ++c)
+            if (cand_off[c + 1] == cand_off[c]) rmse_out[c] = std::numeric_limits<double>::infinity();
+    } while (0);
+    hipFree(d_data); hipFree(d_res); hipFree(d_lines); hipFree(d_off); hipFree(d_out);
+    return r;
+}
+
+int kbdm_silhouette_samples(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* labels, double* out) {
+    if (!ctx || !X || !labels || !out || n < 2 || dim < 1 || dim > KB_SIL_MAXDIM) return fail(KBDM_E_INVALID, "bad silhouette arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    // classes = sorted distinct labels; samples sorted by class (stable)
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return labels[a] < labels[b]; });
+    std::vector<int> cls(n), cstart;
+    int nclass = 0;
+    for (int k = 0; k < n; ++k) {
+        if (k == 0 || labels[order[k]] != labels[order[k - 1]]) { cstart.push_back(k); ++nclass; }
+        cls[k] = nclass - 1;
+    }
+    cstart.push_back(n);
+    if (nclass < 2 || nclass > n - 1) return fail(KBDM_E_INVALID, "number of labels must be in 2 .. n_samples - 1");
+    std::vector<double> xs((size_t)n * dim), so(n);
+    for (int k = 0; k < n; ++k) memcpy(&xs[(size_t)k * dim], &X[(size_t)order[k] * dim], sizeof(double) * dim);
+    double *d_x = nullptr, *d_o = nullptr;
+    int *d_cls = nullptr, *d_cs = nullptr;
+    hipStream_t st = ctx->stream;
+    int r = KBDM_OK;
+    do {
+        if (hipMalloc(&d_x, sizeof(double) * n * dim) != hipSuccess || hipMalloc(&d_o, sizeof(double) * n) != hipSuccess ||
+            hipMalloc(&d_cls, sizeof(int) * n) != hipSuccess || hipMalloc(&d_cs, sizeof(int) * (nclass + 1)) != hipSuccess) {
+            r = fail(KBDM_E_NOMEM, "hipMalloc (silhouette)");
+            break;
+        }
+        hipMemcpyAsync(d_x, xs.data(), sizeof(double) * n * dim, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_cls, cls.data(), sizeof(int) * n, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_cs, cstart.data(), sizeof(int) * (nclass + 1), hipMemcpyHostToDevice, st);
+        hipLaunchKernelGGL(k_silhouette, dim3((n + KB_SIL_TILE - 1) / KB_SIL_TILE), dim3(KB_SIL_TILE), 0, st, d_x, n, dim,
+                           d_cls, d_cs, nclass, d_o);
+        hipMemcpyAsync(so.data(), d_o, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "silhouette kernel failed"); break; }
+        for (int k = 0; k < n; ++k) out[order[k]] = so[k];
+    } while (0);
+    hipFree(d_x); hipFree(d_o); hipFree(d_cls); hipFree(d_cs);
     return r;
 }
 

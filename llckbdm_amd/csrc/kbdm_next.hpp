@@ -1,0 +1,113 @@
+// Kernels for the rows next to the hot path: scoring of candidate line lists and cluster
+// silhouettes.  Included by kbdm_hip.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kb_complex.hpp"
+
+namespace kb {
+
+// ------------------------------------------------------------------------------------
+// Frequency-domain RMSE of candidate line lists (reference metrics.py:7-17 via min_rmse_kbdm.py:33-38):
+//     rmse = sqrt( mean_k ( Re FFT(data)_k / sqrt(N) - Re FFT(est)_k / sqrt(N) )^2 ),
+//     est_n = sum_p A_p exp(-t_n / T2_p) exp(i (2 pi F_p t_n + PH_p)),   t_n = n dwell.
+// With r = data - est and R = FFT(r):  sum_k (Re R_k)^2 = (1/2) sum_k |R_k|^2 + (1/2) Re sum_k R_k^2
+//                                      = (N/2) ( sum_n |r_n|^2 + Re sum_n r_n r_{(N-n) mod N} ),
+// so  rmse^2 = ( sum_n |r_n|^2 + Re sum_n r_n r_{(N-n) mod N} ) / (2 N): no transform is needed.
+// One workgroup per candidate: the residual goes to a scratch row, then the two sums.
+__global__ void __launch_bounds__(256) k_rmse(const cd* __restrict__ data, int N, double dwell,
+                                               const double* __restrict__ lines, const long long* __restrict__ cand_off,
+                                               cd* __restrict__ resid, double* __restrict__ out) {
+    const int c = blockIdx.x;
+    const long long p0 = cand_off[c], p1 = cand_off[c + 1];
+    cd* r = resid + (size_t)c * N;
+    const double twopi = 6.283185307179586476925286766559;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const double t = (double)n * dwell;
+        double er = 0.0, ei = 0.0;
+        for (long long p = p0; p < p1; ++p) {
+            const double A = lines[4 * p], T2 = lines[4 * p + 1], F = lines[4 * p + 2], PH = lines[4 * p + 3];
+            const double env = A * exp(-t / T2);
+            double sn, cs;
+            sincos(twopi * F * t + PH, &sn, &cs);
+            er += env * cs;
+            ei += env * sn;
+        }
+        const cd d = data[n];
+        r[n] = mk(d.x - er, d.y - ei);
+    }
+    __syncthreads();
+    double s = 0.0;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const cd a = r[n], b = r[(N - n) % N];
+        s += a.x * a.x + a.y * a.y + (a.x * b.x - a.y * b.y);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double v = red[0] / (2.0 * (double)N);
+        out[c] = sqrt(v > 0.0 ? v : 0.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Silhouette coefficient of every sample (sklearn.metrics.silhouette_samples semantics, Euclidean
+// metric, as used by the reference's clustering sweep llckbdm.py:291): for sample i of class A
+//   a = mean distance to the other members of A,  b = min over classes C != A of the mean distance to C,
+//   s = (b - a) / max(a, b);  0 for a singleton class (and where max(a, b) = 0).
+// The host passes the samples SORTED by class (xs: n x dim row-major, cls[i], class ranges cstart[L+1]),
+// so a class is a contiguous range and a thread needs one running sum.  One thread per sample, the
+// other samples stream through LDS tiles.  Distances are computed directly (sqrt of the sum of squared
+// differences), not through the |x|^2 - 2 x.y + |y|^2 expansion.
+#define KB_SIL_TILE 256
+#define KB_SIL_MAXDIM 8
+__global__ void __launch_bounds__(KB_SIL_TILE) k_silhouette(const double* __restrict__ xs, int n, int dim,
+                                                             const int* __restrict__ cls, const int* __restrict__ cstart,
+                                                             int nclass, double* __restrict__ out) {
+    __shared__ double tile[KB_SIL_TILE * KB_SIL_MAXDIM];
+    const int i = blockIdx.x * KB_SIL_TILE + threadIdx.x;
+    const bool live = i < n;
+    double xi[KB_SIL_MAXDIM];
+#pragma unroll
+    for (int d = 0; d < KB_SIL_MAXDIM; ++d) xi[d] = (live && d < dim) ? xs[(size_t)i * dim + d] : 0.0;
+    const int mine = live ? cls[i] : -1;
+    double a = 0.0, b = 1.79769313486231570815e308;
+    for (int c = 0; c < nclass; ++c) {
+        const int j0 = cstart[c], j1 = cstart[c + 1];
+        double sum = 0.0;
+        for (int jb = j0; jb < j1; jb += KB_SIL_TILE) {
+            const int cnt = (j1 - jb < KB_SIL_TILE) ? j1 - jb : KB_SIL_TILE;
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < cnt * dim; idx += KB_SIL_TILE) tile[idx] = xs[(size_t)jb * dim + idx];
+            __syncthreads();
+            if (live) {
+                for (int j = 0; j < cnt; ++j) {
+                    double d2 = 0.0;
+#pragma unroll
+                    for (int d = 0; d < KB_SIL_MAXDIM; ++d)
+                        if (d < dim) { const double df = xi[d] - tile[j * dim + d]; d2 = fma(df, df, d2); }
+                    sum += sqrt(d2);
+                }
+            }
+        }
+        const int sz = j1 - j0;
+        if (c == mine) a = (sz > 1) ? sum / (double)(sz - 1) : 0.0;
+        else if (sz > 0) { const double mean = sum / (double)sz; b = mean < b ? mean : b; }
+    }
+    if (live) {
+        const int sz = cstart[mine + 1] - cstart[mine];
+        double s = 0.0;
+        if (sz > 1 && nclass > 1) {
+            const double mx = a > b ? a : b;
+            s = (mx > 0.0) ? (b - a) / mx : 0.0;
+        }
+        out[i] = s;
+    }
+}
+
+}  // namespace kb

@@ -173,6 +173,33 @@ class Engine:
             so += mi
         return out, status
 
+    def rmse_batch(self, data, dwell, candidates):
+        """Frequency-domain RMSE (reference metrics.py:7-17) of every candidate line list against `data`;
+        an empty candidate scores +inf (min_rmse_kbdm.py:36-37).  One GPU call for all candidates."""
+        data = np.ascontiguousarray(data, dtype=np.complex128).ravel()
+        cands = [np.ascontiguousarray(np.asarray(c, dtype=np.float64).reshape(-1, 4)) for c in candidates]
+        off = np.zeros(len(cands) + 1, dtype=np.int64)
+        for i, c in enumerate(cands):
+            off[i + 1] = off[i] + len(c)
+        lines = np.concatenate(cands) if cands and off[-1] > 0 else np.zeros((1, 4))
+        lines = np.ascontiguousarray(lines, dtype=np.float64)
+        out = np.empty(len(cands), dtype=np.float64)
+        _lib.check(self.lib.kbdm_rmse_batch(self.ctx, _lib.ptr(data), int(data.size), float(dwell), _lib.ptr(lines),
+                                            _lib.ptr(off), len(cands), _lib.ptr(out)))
+        return out
+
+    def silhouette_samples(self, X, labels):
+        """Silhouette coefficient of every sample, Euclidean metric (sklearn.metrics.silhouette_samples as used
+        at llckbdm.py:291), computed on the GPU with directly evaluated distances."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if X.ndim != 2 or labels.shape != (X.shape[0],):
+            raise ValueError("X must be (n, dim) and labels (n,)")
+        out = np.empty(X.shape[0], dtype=np.float64)
+        _lib.check(self.lib.kbdm_silhouette_samples(self.ctx, _lib.ptr(X), X.shape[0], X.shape[1], _lib.ptr(labels),
+                                                    _lib.ptr(out)))
+        return out
+
     def eig(self, mats):
         n = np.array([a.shape[0] for a in mats], dtype=np.int32)
         flat = np.concatenate([np.ascontiguousarray(a, dtype=np.complex128).ravel() for a in mats])
