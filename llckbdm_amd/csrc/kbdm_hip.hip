@@ -75,7 +75,7 @@ struct kbdm_ctx {
     int split_invit = 8;  // workgroups per item in k_invit
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
-    int team_max = 96;    // teams per launch: 2 workgroups each, one workgroup per CU, all resident
+    int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
 };
 
@@ -412,11 +412,13 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         // Large members of the critical lane run as two-workgroup teams (k_hqr_team); the remaining
         // members of the chunk run solo on the side stream (after k_gen(Qh)), concurrently.
         int nteam = 0;
-        if (ctx->team_hqr && ch.lane == 0 && win > 0 && ln.stream2 != ln.stream) {
-            while (nteam < ch.count && nteam < ctx->team_max && pl->items[pl->perm[ch.first + nteam]].l >= ctx->team_min_l) ++nteam;
+        if (ctx->team_hqr && win > 0 && ln.stream2 != ln.stream) {
+            int nside = 0;                                   // lanes that may run teams share the budget of resident teams
+            for (int i = 0; i < ctx->nlanes; ++i) nside += (ctx->lanes[i].stream2 != ctx->lanes[i].stream) ? 1 : 0;
+            const int cap = std::max(1, ctx->team_max / std::max(1, nside));
+            while (nteam < ch.count && nteam < cap && pl->items[pl->perm[ch.first + nteam]].l >= ctx->team_min_l) ++nteam;
         }
         if (nteam > 0) {
-            HIPCHK(hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * pl->B, st));
             hipLaunchKernelGGL(k_hqr_team, dim3(2 * nteam), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
                                pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, pl->d_team, pl->d_rings, prof);
         }
@@ -527,14 +529,18 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     kbdm_ctx* c = new kbdm_ctx();
     c->device = device;
     c->nlanes = std::min(KB_MAX_LANES, std::max(1, env_int("KBDM_LANES", c->nlanes)));
+    const int hwq = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
+    const bool side_all = env_int("KBDM_SIDE_ALL", 0) != 0;
     for (int i = 0; i < c->nlanes; ++i) {
         Lane& ln = c->lanes[i];
         HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-        // Only the critical lane gets a side stream of its own: streams beyond the hardware queue
-        // count share queues, and two lanes whose replay kernels wait (in-kernel flags) on generator
-        // kernels queued behind each other would never finish.  On the other lanes the side work
-        // simply runs in stream order.
-        if (i == 0) HIPCHK(hipStreamCreateWithFlags(&ln.stream2, hipStreamNonBlocking));
+        // Side streams only while every stream still has a hardware queue of its own (GPU_MAX_HW_QUEUES,
+        // 4 by default): streams beyond that share queues, and two lanes whose replay kernels wait
+        // (in-kernel flags) on generator kernels queued behind each other would never finish.  A lane
+        // without a side stream runs its side work in stream order (and its QR iteration solo).
+        // (Measured: side streams / teams on the other lanes as well slow the critical lane down more than
+        // they speed those lanes up - C2 182 ms instead of 175 - so they are opt-in: KBDM_SIDE_ALL=1.)
+        if (i == 0 || (side_all && c->nlanes + i + 1 <= hwq)) HIPCHK(hipStreamCreateWithFlags(&ln.stream2, hipStreamNonBlocking));
         else ln.stream2 = ln.stream;
         HIPCHK(hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
@@ -630,6 +636,7 @@ int kbdm_plan_execute(kbdm_plan* pl) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemsetAsync(pl->d_status, 0, sizeof(int) * pl->B, st));
     HIPCHK(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * 4 * pl->B, st));
+    HIPCHK(hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * pl->B, st));
     // groups one after the other (they share the arena); inside a group one chunk per lane, all
     // lanes concurrently: fork from the main stream, join back into it
     size_t ci = 0;
@@ -843,6 +850,7 @@ int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, doub
         if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
         hipMemcpy(d_dense, W, sizeof(cd) * tot, hipMemcpyHostToDevice);
         hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
+        hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * B, st);
         Chunk& ch = pl->chunks[0];
         hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_P, 1);
         hipLaunchKernelGGL(k_fill_ones, dim3(B), dim3(256), 0, st, pl->d_items, pl->d_varena);
