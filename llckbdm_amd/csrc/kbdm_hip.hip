@@ -65,6 +65,7 @@ struct kbdm_ctx {
     Lane lanes[KB_MAX_LANES];
     hipEvent_t ev_start = nullptr;
     int nlanes = 2;
+    double lane0_frac = 0.5;   // share of the batch's cost (sum of m^3) that lane 0 takes when there are two lanes
     int nt_fac = 1024;    // threads per workgroup: bidiagonalisation / Hessenberg kernels
     int nt_bdsqr = 1024;
     int nt_hqr = 512;
@@ -224,7 +225,7 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
             for (int ln = 0; ln < nl; ++ln) {
                 Chunk c;
                 c.group = g.group; c.lane = ln; c.first = g.first + pos;
-                const double upto = total * (ln + 1) / nl;
+                const double upto = (nl == 2) ? total * (ln == 0 ? ctx->lane0_frac : 1.0) : total * (ln + 1) / nl;
                 while (pos < g.count && (ln == nl - 1 || acc < upto || c.count == 0)) {
                     const KbItem& it = pl->items[pl->perm[g.first + pos]];
                     acc += (double)it.m * it.m * it.m;
@@ -412,7 +413,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         // Large members of the critical lane run as two-workgroup teams (k_hqr_team); the remaining
         // members of the chunk run solo on the side stream (after k_gen(Qh)), concurrently.
         int nteam = 0;
-        if (ctx->team_hqr && win > 0 && ln.stream2 != ln.stream) {
+        if (ctx->team_hqr && win > 0 && ln.stream2 != ln.stream && (ch.lane == 0 || ctx->team_hqr > 1)) {
             int nside = 0;                                   // lanes that may run teams share the budget of resident teams
             for (int i = 0; i < ctx->nlanes; ++i) nside += (ctx->lanes[i].stream2 != ctx->lanes[i].stream) ? 1 : 0;
             const int cap = std::max(1, ctx->team_max / std::max(1, nside));
@@ -531,6 +532,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->nlanes = std::min(KB_MAX_LANES, std::max(1, env_int("KBDM_LANES", c->nlanes)));
     const int hwq = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
     const bool side_all = env_int("KBDM_SIDE_ALL", 0) != 0;
+    if (const char* v = getenv("KBDM_LANE0_FRAC")) c->lane0_frac = std::min(0.95, std::max(0.05, atof(v)));
     for (int i = 0; i < c->nlanes; ++i) {
         Lane& ln = c->lanes[i];
         HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
