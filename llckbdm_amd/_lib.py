@@ -11,6 +11,12 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libkbdm_hip.so")
 
+# A plan runs on three HIP streams (two lanes + the critical lane's side stream).  The ROCm runtime maps streams
+# onto four hardware queues by default; once torch / RCCL streams are added they would share queues, which
+# serialises the lanes.  Effective only if HIP has not been initialised in this process yet; never overrides the
+# user's own setting.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 KBDM_ABI_VERSION = 1
 KBDM_NSTAGES = 16
 STAT_SVD_NOCONV, STAT_EIG_NOCONV, STAT_INVIT_WEAK = 1, 2, 4
