@@ -388,13 +388,17 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                            pl->d_varena, sm, npan > 0 ? 1 : 0);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
-    // Qh is first needed by k_gemm<3>: accumulate it on the side stream while the QR iteration runs.
+    // Qh is first needed by k_gemm<3>: accumulate it on a side stream while the QR iteration runs.  A lane
+    // without a side stream of its own borrows the critical lane's, which is idle during the QR iteration
+    // (a stream of this lane's own would cost a hardware queue; in stream order k_gen(Qh) would sit in front
+    // of the QR iteration: 6.6 ms of the non-critical lane's chain on C2).
+    hipStream_t qs = (ln.stream2 != ln.stream) ? ln.stream2 : ctx->lanes[0].stream2;
     HIPCHK(hipEventRecord(ln.ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(ln.stream2, ln.ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(qs, ln.ev_fork, 0));
     {
-        int r = launch_gen(pl, ch, ch.lmax, 1, 1, ln.stream2);
+        int r = launch_gen(pl, ch, ch.lmax, 1, 1, qs);
         if (r) return r;
-        HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));
+        HIPCHK(hipEventRecord(ln.ev_join, qs));
         if (tm) { r = tm->mark(); if (r) return r; }      // k_gen(Qh) slot (overlapped with k_hqr)
     }
     {
