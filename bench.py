@@ -198,7 +198,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/), if any
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_stream_pmc_traffic.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_end_pmc_traffic.json")))["kernels"]
             # lane 0 runs the QR iteration as k_hqr_team; k_gen is templated on the register chunk count
             for key in (dom + "_team", dom, dom.split("(")[0], dom.split("(")[0] + "<8>"):
                 if key in pmc:
