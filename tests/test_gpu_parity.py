@@ -193,6 +193,37 @@ def test_batch_against_oracle_on_seeded_inputs(eng):
         assert_lines_close(k, w, rel=1e-8, phase_abs=1e-8, what=f"item {i}")
 
 
+def test_bench_workload_members_against_oracle(eng):
+    """The benchmark's own batch (BASELINE.json configs[1]: 151 members, m = 100..400:2, sigma = 1e-3 noise), run
+    exactly as bench.py runs it - two lanes, team kernels for the large members, streaming replay following the
+    generators - with members from both lanes and both ends of each lane compared with the oracle: equal
+    kept-line counts, every kept line to 1e-8 (1e-6 for the weakest spurious lines), singular values to eps*m*s0.
+    Full size, so the oracle is only run on five members."""
+    from llckbdm_amd import datasets
+    sigs, sig_idx, ms = datasets.config2(seed=0)
+    res = eng.solve(sigs, sig_idx, ms, ms, p=1, q=0.0, dwell=datasets.DWELL)
+    assert not (res.status & 3).any()
+    ms = list(ms)
+    for m in (100, 238, 336, 338, 400):
+        i = ms.index(m)
+        want, info = O.kbdm(sigs[0], datasets.DWELL, m=m, normalizer="gemm")
+        got = res.line_list(i)
+        assert np.array_equal(res.keep_mask(i), keep_mask(got))
+        assert np.abs(res.singular_values(i) - info.singular_values).max() < 1e-14 * info.singular_values[0] * m
+        k, w = canonical(got[keep_mask(got)]), canonical(O.filter_samples(want))
+        assert len(k) == len(w), f"m={m}: kept {len(k)} vs {len(w)}"
+        strong = w[:, 0] > 1e-4
+        assert_lines_close(k[strong], w[strong], rel=1e-8, phase_abs=1e-8, what=f"m={m} strong")
+        assert_lines_close(k, w, rel=1e-6, phase_abs=1e-6, what=f"m={m} all")
+    # size-independent property at full size: a member's result does not depend on what else is in the batch
+    # (different lane, different team / solo kernel, different replay grouping): bit for bit
+    for m in (400, 250):
+        solo = eng.solve(sigs, [0], [m], [m], p=1, q=0.0, dwell=datasets.DWELL)
+        i = ms.index(m)
+        assert np.array_equal(solo.line_list(0), res.line_list(i))
+        assert np.array_equal(solo.singular_values(0), res.singular_values(i))
+
+
 def test_pseudo_noise_ensemble_properties(eng):
     """Config-3 shape at reduced count: fixed m, one noise draw per member.  Size-independent
     checks: every member recovers the 16 true peaks; members are independent of batch position."""
