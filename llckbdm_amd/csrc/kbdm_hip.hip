@@ -72,7 +72,7 @@ struct kbdm_ctx {
     int nt_invit = 1024;
     int ns_hqr = 8;       // simultaneous shifts (bulges) of the QR iteration
     int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
-    int split_gen = 4;    // workgroups per item and matrix in k_gen
+    int split_gen = 32;   // workgroups per item and matrix in k_gen (columns of one matrix are independent)
     int split_invit = 8;  // workgroups per item in k_invit
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
