@@ -32,6 +32,12 @@ struct DevCtx {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
+    // order this wavefront's LDS writes before later LDS reads by its other lanes WITHOUT waiting for its
+    // outstanding global stores (wave_fence waits for their acknowledgement: hundreds of cycles per use)
+    __device__ __forceinline__ void lds_fence() const {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
     __device__ __forceinline__ char* scratch() const { return smem + KB_RED_BYTES; }
     __device__ __forceinline__ int scratch_bytes() const { return smem_bytes - KB_RED_BYTES; }
 
@@ -139,6 +145,7 @@ struct HostCtx {
     int nwaves() const { return 1; }
     void sync() const {}
     void wave_fence() const {}
+    void lds_fence() const {}
     char* scratch() const { return smem + KB_RED_BYTES; }
     int scratch_bytes() const { return smem_bytes - KB_RED_BYTES; }
     double wave_sum(double v) const { return v; }
