@@ -608,4 +608,164 @@ KB_HD void invit(const C& ctx, int n, const cd* H, int ldh, const cd* w, double 
     if (lane == 0 && nweak > 0) *weak = 1;   // benign race: every writer stores 1
 }
 
+#if defined(__HIPCC__)
+// Register-resident inverse iteration (device only): the same elimination and the same arithmetic as
+// `invit` above, but the three O(n) vectors of a solve (candidate column, right-hand side, multipliers) live
+// in the REGISTERS of the wavefront - element r on lane r mod 64, chunk r / 64 - instead of LDS: a value at a
+// known position is broadcast with v_readlane, no LDS traffic, no fences, and no LDS footprint, so many
+// wavefronts share a CU (the LDS form holds 19 KB per solve at n = 400: eight wavefronts per CU).
+// The chunk of the pivot position is a compile-time index (outer loops over chunks are unrolled), so every
+// register access is static.  n <= MAXC * 64.
+__device__ __forceinline__ cd kb_bcast(cd v, int l) {
+    return mk(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.x), l), __builtin_amdgcn_readlane(__double2loint(v.x), l)),
+              __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.y), l), __builtin_amdgcn_readlane(__double2loint(v.y), l)));
+}
+
+template <int MAXC>
+__device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, int ldh, const cd* __restrict__ w,
+                          double hnorm, cd* __restrict__ X, int ldx, int kk_begin, int kk_step, int* weak) {
+    const int lane = ctx.lane();
+    const double eps3 = fmax(hnorm * KB_ULP, KB_SAFMIN * ((double)n / KB_ULP));
+    const double rootn = sqrt((double)n);
+    const double growto = 0.1 / rootn;
+    int nweak = 0;
+    for (int kk = kk_begin; kk < n; kk += kk_step) {
+        cd wk = w[kk];
+        {
+            int cnt = 0;
+            for (int q = lane; q < kk; q += 64) cnt += (cabs1(w[q] - w[kk]) < eps3) ? 1 : 0;
+            cnt = (int)ctx.wave_sum((double)cnt);
+            wk.x += cnt * eps3;
+        }
+        cd cand[MAXC], bv[MAXC], fm[MAXC];
+        unsigned swp = 0;                  // bit c: swap flag of element lane + 64 c
+        bool ok = false;
+        for (int its = 0; its < 4 && !ok; ++its) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int r = lane + 64 * c;
+                double vj;
+                if (its == 0) vj = eps3;
+                else {
+                    const double rtemp = eps3 / (rootn + 1.0);
+                    vj = (r == 0) ? eps3 : rtemp;
+                    if (r == n - its) vj -= eps3 * rootn;
+                }
+                bv[c] = mk(vj, 0.0);
+                cd v = (r < n) ? H[r + (size_t)(n - 1) * ldh] : czero();
+                if (r == n - 1) v = v - wk;
+                cand[c] = v;
+                fm[c] = czero();
+            }
+            swp = 0;
+            bool rescaled = false;
+            cd nxt[MAXC];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int r = lane + 64 * c;
+                nxt[c] = (n >= 2 && r <= n - 1) ? H[r + (size_t)(n - 2) * ldh] : czero();
+            }
+            // position p = j + 1 runs from n-1 down to 1; cj = chunk of p (compile time)
+#pragma unroll
+            for (int cj = MAXC - 1; cj >= 0; --cj) {
+                const int phi = (n - 1 < 64 * cj + 63) ? n - 1 : 64 * cj + 63;
+                const int plo = (64 * cj > 1) ? 64 * cj : 1;
+                for (int p = phi; p >= plo; --p) {
+                    const int j = p - 1, lp = p - 64 * cj;
+                    cd cur[MAXC];
+#pragma unroll
+                    for (int c = 0; c <= cj; ++c) cur[c] = nxt[c];
+                    if (j >= 1) {
+#pragma unroll
+                        for (int c = 0; c <= cj; ++c) {
+                            const int r = lane + 64 * c;
+                            nxt[c] = (r <= j) ? H[r + (size_t)(j - 1) * ldh] : czero();
+                        }
+                    }
+                    const cd rsub = kb_bcast(cur[cj], lp);        // B(j+1, j) = H(j+1, j)
+                    cd cpiv = kb_bcast(cand[cj], lp);             // diagonal of the candidate
+                    const cd bp = kb_bcast(bv[cj], lp);
+                    cd f, piv;
+                    const bool swap = cabs1(cpiv) < cabs1(rsub);
+                    if (!swap) {
+                        if (is_zero(cpiv)) cpiv = mk(eps3, 0.0);
+                        piv = cpiv;
+                        f = cdiv(rsub, cpiv);
+                    } else {
+                        piv = rsub;
+                        f = cdiv(cpiv, rsub);
+                    }
+                    const cd yj1 = cdiv(bp, piv);
+#pragma unroll
+                    for (int c = 0; c <= cj; ++c) {
+                        const int r = lane + 64 * c;
+                        if (r <= j) {
+                            cd raw = cur[c];
+                            if (r == j) raw = raw - wk;
+                            const cd cn = cand[c];
+                            const cd fin = swap ? raw : cn;
+                            const cd oth = swap ? cn : raw;
+                            cand[c] = oth - f * fin;          // new candidate for position j
+                            bv[c] = bv[c] - yj1 * fin;
+                        }
+                        if (r == p) bv[c] = yj1;
+                        if (r == j) { fm[c] = f; swp = swap ? (swp | (1u << c)) : (swp & ~(1u << c)); }
+                    }
+                    if (cabs1(yj1) > 1e120) {                  // guard against overflow: rescale the whole system
+#pragma unroll
+                        for (int c = 0; c < MAXC; ++c) bv[c] = bv[c] * 1e-120;
+                        rescaled = true;
+                    }
+                }
+            }
+            {
+                cd p0 = kb_bcast(cand[0], 0);
+                if (is_zero(p0)) p0 = mk(eps3, 0.0);
+                const cd y0 = cdiv(kb_bcast(bv[0], 0), p0);
+                // x = E_{n-2} ... E_0 y : E_j acts on coordinates (j, j+1); one value is carried
+                cd carry = y0;
+#pragma unroll
+                for (int cj = 0; cj < MAXC; ++cj) {
+                    const int jhi = (n - 2 < 64 * cj + 63) ? n - 2 : 64 * cj + 63;
+                    for (int j = 64 * cj; j <= jhi; ++j) {
+                        const int lj = j - 64 * cj;
+                        const cd f = kb_bcast(fm[cj], lj);
+                        const bool sw = (__builtin_amdgcn_readlane((int)swp, lj) >> cj) & 1;
+                        cd b;
+                        if (lj < 63) b = kb_bcast(bv[cj], lj + 1);
+                        else b = kb_bcast(bv[(cj + 1 < MAXC) ? cj + 1 : cj], 0);
+                        const cd t = b - f * carry;
+                        const cd xj = sw ? t : carry;
+                        if (!sw) carry = t;
+                        if (lane == lj) bv[cj] = xj;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (lane + 64 * c == n - 1) bv[c] = carry;
+            }
+            double vn = 0.0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (lane + 64 * c < n) vn += cabs1(bv[c]);
+            vn = ctx.wave_sum(vn);
+            ok = rescaled || (vn >= growto);
+        }
+        if (!ok) nweak++;
+        double mx = 0.0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + 64 * c < n) mx = fmax(mx, cabs1(bv[c]));
+        mx = ctx.wave_max(mx);
+        const double inv = (mx > 0.0) ? 1.0 / mx : 1.0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int r = lane + 64 * c;
+            if (r < n) X[r + (size_t)kk * ldx] = bv[c] * inv;
+        }
+    }
+    if (lane == 0 && nweak > 0) *weak = 1;   // benign race: every writer stores 1
+}
+#endif
+
 }  // namespace kb

@@ -74,6 +74,7 @@ struct kbdm_ctx {
     int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
     int split_gen = 32;   // workgroups per item and matrix in k_gen (columns of one matrix are independent)
     int split_invit = 8;  // workgroups per item in k_invit
+    int invit_reg = 1;    // inverse iteration with register-resident vectors for l <= 512 (0: the LDS form)
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
@@ -452,6 +453,17 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (nw < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
         const int sm = KB_RED_BYTES + nw * per;
         HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // eigenvalues of the solo members (side stream) and Qh
+        if (ctx->invit_reg && ch.lmax <= 512) {
+            // register-resident solves: no LDS; enough wavefronts that every one solves about two eigenvalues
+            const int wpb = 8;
+            int split = (ch.lmax + 2 * wpb - 1) / (2 * wpb);
+            split = std::max(1, std::min(split, 64));
+            dim3 grid(ch.count, split), block(64 * wpb);
+            const int chunks = (ch.lmax + 63) / 64;
+            if (chunks <= 2) hipLaunchKernelGGL(k_invit_reg<2>, grid, block, 0, st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
+            else if (chunks <= 4) hipLaunchKernelGGL(k_invit_reg<4>, grid, block, 0, st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
+            else hipLaunchKernelGGL(k_invit_reg<8>, grid, block, 0, st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
+        } else
         hipLaunchKernelGGL(k_invit, dim3(ch.count, ctx->split_invit), dim3(ctx->nt_invit), sm, st, pl->d_items, perm,
                            pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm);
         HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // Qh ready before k_gemm<3>
@@ -565,6 +577,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
     c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
+    c->invit_reg = env_int("KBDM_INVIT_REG", c->invit_reg);
     c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
     c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
     if (c->nt_hqr > 512) c->nt_hqr = 512;

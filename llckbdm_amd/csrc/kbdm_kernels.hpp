@@ -588,6 +588,29 @@ __global__ void __launch_bounds__(1024) k_invit(const KbItem* __restrict__ items
     if (threadIdx.x == 0 && weak) atomicOr(&status[item], KB_STAT_INVIT_WEAK);
 }
 
+// Register-resident form (members with l <= 64 MAXC): no LDS, 512-thread workgroups, every wavefront solves
+// the eigenvalues kk = (global wavefront index), + (wavefronts per member), ...
+template <int MAXC>
+__global__ void __launch_bounds__(512) k_invit_reg(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                    cd* arena, double* varena, const cd* mu_out, int* status) {
+    const int item = perm[blockIdx.x];
+    const KbItem it = items[item];
+    const int n = it.l;
+    if (n > MAXC * 64) return;                       // host picks MAXC from the largest member of the launch
+    const DevCtx ctx = make_ctx(0);
+    const cd* Hw = arena + it.off[KB_BUF_P];
+    cd* X = arena + it.off[KB_BUF_H];
+    const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
+    __shared__ int weak;
+    if (threadIdx.x == 0) weak = 0;
+    __syncthreads();
+    const int wpb = blockDim.x >> 6;
+    invit_reg<MAXC>(ctx, n, Hw, n, mu_out + it.line_off, hnorm, X, n, (int)blockIdx.y * wpb + ctx.wave(),
+                    (int)gridDim.y * wpb, &weak);
+    __syncthreads();
+    if (threadIdx.x == 0 && weak) atomicOr(&status[item], KB_STAT_INVIT_WEAK);
+}
+
 // ------------------------------------------------------------------------------------
 // Epilogue (kbdm.py:71-90 + sampling.py:75-97).  One wavefront per spectral line k:
 //   N_k = sum_i B[i,k] T[i,k]   (bilinear, unconjugated)      D_sqrt = c[:m] . b_k / sqrt(N_k)
