@@ -128,6 +128,20 @@ int kbdm_rmse_batch(kbdm_ctx* ctx, const double* data, int N, double dwell, cons
  * out[n].  Needs at least 2 classes and at most n - 1 (sklearn's precondition). */
 int kbdm_silhouette_samples(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* labels, double* out);
 
+/* HDBSCAN* for every value of `min_samples` of the clustering sweep at once: replaces the loop of
+ * `hdbscan.HDBSCAN(min_samples=k).fit(X).labels_` at llckbdm/llckbdm.py:104-110,280-283 (Euclidean, alpha 1,
+ * excess of mass, no single-cluster result; semantics of scikit-learn's HDBSCAN: the point itself counts towards
+ * min_samples).  X: n x dim float64 row-major (dim <= 8); min_samples[nfits] (1 <= k <= n);
+ * labels_out[nfits * n] (-1 = noise), nclusters_out[nfits] (may be null).  The O(n^2) parts (k-nearest-neighbour
+ * distances once for all fits, one Prim MST per fit, all fits concurrently) run on the GPU, the trees on the host. */
+int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* min_samples, int nfits,
+                       int min_cluster_size, int32_t* labels_out, int32_t* nclusters_out);
+
+/* The host half on its own (no GPU): labels from the n-1 edges (a[i], b[i], w[i]) of a minimum spanning tree of the
+ * mutual-reachability graph.  Returns the number of clusters. */
+int kbdm_hdbscan_labels_from_mst(int n, const int32_t* a, const int32_t* b, const double* w, int min_cluster_size,
+                                 int32_t* labels_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,8 @@ SYMBOLS = {
     "kbdm_plan_lane0_members": (c_int, [_P]),
     "kbdm_rmse_batch": (c_int, [_P, _P, c_int, c_double, _P, _P, c_int, _P]),
     "kbdm_silhouette_samples": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "kbdm_hdbscan_sweep": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P]),
+    "kbdm_hdbscan_labels_from_mst": (c_int, [c_int, _P, _P, _P, c_int, _P]),
     "kbdm_solve_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_double, c_double,
                                  _P, _P, _P, _P, _P]),
     "kbdm_hankel_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),

@@ -11,11 +11,13 @@
 #include <numeric>
 #include <string>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/kbdm_hip.h"
 #include "kbdm_kernels.hpp"
 #include "kbdm_next.hpp"
+#include "kbdm_cluster.hpp"
 
 using namespace kb;
 
@@ -960,6 +962,70 @@ int kbdm_silhouette_samples(kbdm_ctx* ctx, const double* X, int n, int dim, cons
     } while (0);
     hipFree(d_x); hipFree(d_o); hipFree(d_cls); hipFree(d_cs);
     return r;
+}
+
+int kbdm_hdbscan_labels_from_mst(int n, const int32_t* a, const int32_t* b, const double* w, int min_cluster_size,
+                                 int32_t* labels_out) {
+    if (n < 1 || !labels_out || (n > 1 && (!a || !b || !w)) || min_cluster_size < 2) return fail(KBDM_E_INVALID, "bad mst arguments");
+    std::vector<MstEdge> e(std::max(n - 1, 0));
+    for (int i = 0; i < n - 1; ++i) {
+        if (a[i] < 0 || a[i] >= n || b[i] < 0 || b[i] >= n) return fail(KBDM_E_INVALID, "mst edge out of range");
+        e[i] = MstEdge{a[i], b[i], w[i]};
+    }
+    return hdbscan_labels_from_mst(n, e.data(), min_cluster_size, labels_out);
+}
+
+int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* min_samples, int nfits,
+                       int min_cluster_size, int32_t* labels_out, int32_t* nclusters_out) {
+    if (!ctx || !X || !min_samples || !labels_out || n < 2 || dim < 1 || dim > KB_SIL_MAXDIM || nfits < 1 || min_cluster_size < 2)
+        return fail(KBDM_E_INVALID, "bad hdbscan arguments");
+    int K = 1;
+    for (int f = 0; f < nfits; ++f) {
+        if (min_samples[f] < 1 || min_samples[f] > n) return fail(KBDM_E_INVALID, "min_samples out of range");
+        K = std::max(K, (int)min_samples[f]);
+    }
+    const size_t lds = ((size_t)K * KB_KNN_TPB + (size_t)KB_KNN_TPB * KB_SIL_MAXDIM) * sizeof(double);
+    if (lds > (size_t)LDS_MAX - 64) return fail(KBDM_E_NOMEM, "min_samples too large for the k-nearest-neighbour kernel");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_dist), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    double *d_x = nullptr, *d_knn = nullptr, *d_best = nullptr, *d_core = nullptr;
+    int *d_ms = nullptr, *d_src = nullptr;
+    KbEdge* d_edges = nullptr;
+    hipStream_t st = ctx->stream;
+    std::vector<KbEdge> edges((size_t)nfits * (n - 1));
+    int r = KBDM_OK;
+    do {
+        if (hipMalloc(&d_x, sizeof(double) * n * dim) != hipSuccess || hipMalloc(&d_knn, sizeof(double) * (size_t)n * K) != hipSuccess ||
+            hipMalloc(&d_best, sizeof(double) * (size_t)n * nfits) != hipSuccess || hipMalloc(&d_core, sizeof(double) * (size_t)n * nfits) != hipSuccess ||
+            hipMalloc(&d_src, sizeof(int) * (size_t)n * nfits) != hipSuccess ||
+            hipMalloc(&d_ms, sizeof(int) * nfits) != hipSuccess || hipMalloc(&d_edges, sizeof(KbEdge) * (size_t)nfits * (n - 1)) != hipSuccess) {
+            r = fail(KBDM_E_NOMEM, "hipMalloc (hdbscan)");
+            break;
+        }
+        hipMemcpyAsync(d_x, X, sizeof(double) * n * dim, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_ms, min_samples, sizeof(int) * nfits, hipMemcpyHostToDevice, st);
+        hipLaunchKernelGGL(k_knn_dist, dim3((n + KB_KNN_TPB - 1) / KB_KNN_TPB), dim3(KB_KNN_TPB), lds, st, d_x, n, dim, K, d_knn);
+        hipLaunchKernelGGL(k_prim_mst, dim3(nfits), dim3(1024), 0, st, d_x, n, dim, K, d_knn, d_ms, d_best, d_core, d_src, d_edges);
+        hipMemcpyAsync(edges.data(), d_edges, sizeof(KbEdge) * edges.size(), hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "hdbscan kernels failed"); break; }
+    } while (0);
+    hipFree(d_x); hipFree(d_knn); hipFree(d_best); hipFree(d_core); hipFree(d_src); hipFree(d_ms); hipFree(d_edges);
+    if (r) return r;
+    // the trees: independent per fit, a few host threads
+    const int nthreads = std::max(1, std::min(nfits, std::min(16, (int)std::thread::hardware_concurrency())));
+    std::vector<std::thread> pool;
+    for (int tix = 0; tix < nthreads; ++tix)
+        pool.emplace_back([&, tix]() {
+            std::vector<MstEdge> e(n - 1);
+            for (int f = tix; f < nfits; f += nthreads) {
+                const KbEdge* src = edges.data() + (size_t)f * (n - 1);
+                for (int i = 0; i < n - 1; ++i) e[i] = MstEdge{src[i].a, src[i].b, src[i].w};
+                const int nc = hdbscan_labels_from_mst(n, e.data(), min_cluster_size, labels_out + (size_t)f * n);
+                if (nclusters_out) nclusters_out[f] = nc;
+            }
+        });
+    for (auto& th : pool) th.join();
+    return KBDM_OK;
 }
 
 }  // extern "C"

@@ -111,3 +111,125 @@ __global__ void __launch_bounds__(KB_SIL_TILE) k_silhouette(const double* __rest
 }
 
 }  // namespace kb
+
+namespace kb {
+
+// ------------------------------------------------------------------------------------
+// HDBSCAN sweep, the O(n^2) parts (the tree part is host code: kbdm_cluster.hpp).
+//
+// k_knn_dist: for every sample the K smallest distances to the samples (itself included, so entry 0 is 0),
+// ascending: knn[i * K + q].  One thread per sample; the running top-K of a thread lives in LDS laid out
+// [q][thread] (conflict-free); candidates stream through registers from an LDS tile; a candidate is inserted only
+// if it beats the current K-th best (after the first few tiles that is rare).
+#define KB_KNN_TPB 64
+__global__ void __launch_bounds__(KB_KNN_TPB) k_knn_dist(const double* __restrict__ xs, int n, int dim, int K,
+                                                          double* __restrict__ knn) {
+    extern __shared__ double kb_knn_lds[];
+    double* top = kb_knn_lds;                                  // K x TPB
+    double* tile = kb_knn_lds + (size_t)K * KB_KNN_TPB;        // TPB x MAXDIM
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * KB_KNN_TPB + t;
+    const bool live = i < n;
+    double xi[KB_SIL_MAXDIM];
+#pragma unroll
+    for (int d = 0; d < KB_SIL_MAXDIM; ++d) xi[d] = (live && d < dim) ? xs[(size_t)i * dim + d] : 0.0;
+    const double inf = 1.79769313486231570815e308;
+    for (int q = 0; q < K; ++q) top[q * KB_KNN_TPB + t] = inf;
+    double kth = inf;                                          // current K-th best of this thread
+    for (int jb = 0; jb < n; jb += KB_KNN_TPB) {
+        const int cnt = (n - jb < KB_KNN_TPB) ? n - jb : KB_KNN_TPB;
+        __syncthreads();
+        for (int idx = t; idx < cnt * dim; idx += KB_KNN_TPB) tile[idx] = xs[(size_t)jb * dim + idx];
+        __syncthreads();
+        if (live) {
+            for (int j = 0; j < cnt; ++j) {
+                double d2 = 0.0;
+#pragma unroll
+                for (int d = 0; d < KB_SIL_MAXDIM; ++d)
+                    if (d < dim) { const double df = xi[d] - tile[j * dim + d]; d2 = fma(df, df, d2); }
+                const double dj = sqrt(d2);
+                if (dj < kth) {
+                    // insert into the ascending list (shift the tail down by one)
+                    int q = K - 1;
+                    while (q > 0 && top[(q - 1) * KB_KNN_TPB + t] > dj) { top[q * KB_KNN_TPB + t] = top[(q - 1) * KB_KNN_TPB + t]; --q; }
+                    top[q * KB_KNN_TPB + t] = dj;
+                    kth = top[(K - 1) * KB_KNN_TPB + t];
+                }
+            }
+        }
+    }
+    if (live)
+        for (int q = 0; q < K; ++q) knn[(size_t)i * K + q] = top[q * KB_KNN_TPB + t];
+}
+
+// k_prim_mst: one workgroup per fit (value of min_samples): Prim's algorithm from sample 0 over the complete graph
+// with mutual-reachability weights max(core_i, core_j, |x_i - x_j|), core_i = knn[i*K + min_samples - 1].
+// Thread t owns samples t, t + nt, ...; per step every thread relaxes its samples against the sample just added
+// and proposes its closest outside sample; a workgroup argmin (ties: lowest index) picks the next one.
+// scratch per fit: best, core (n doubles each), src (n ints); edges per fit: n - 1 records (a, b, w).
+struct KbEdge { int a, b; double w; };
+__global__ void __launch_bounds__(1024) k_prim_mst(const double* __restrict__ xs, int n, int dim, int K,
+                                                    const double* __restrict__ knn, const int* __restrict__ min_samples,
+                                                    double* __restrict__ best_all, double* __restrict__ core_all,
+                                                    int* __restrict__ src_all, KbEdge* __restrict__ edges_all) {
+    const int fit = blockIdx.x;
+    const int ks = min_samples[fit];
+    double* best = best_all + (size_t)fit * n;
+    double* core = core_all + (size_t)fit * n;                 // contiguous copy of column ks - 1 of knn
+    int* src = src_all + (size_t)fit * n;
+    KbEdge* edges = edges_all + (size_t)fit * (n - 1);
+    const int t = threadIdx.x, nt = blockDim.x;
+    const double inf = 1.79769313486231570815e308;
+    __shared__ double red_v[16];
+    __shared__ int red_i[16];
+    __shared__ double xnew[KB_SIL_MAXDIM + 1];
+    __shared__ int cur_s;
+    for (int i = t; i < n; i += nt) {
+        best[i] = (i == 0) ? -1.0 : inf;                       // best < 0: in the tree
+        src[i] = 0;
+        core[i] = knn[(size_t)i * K + ks - 1];
+    }
+    if (t == 0) cur_s = 0;
+    __syncthreads();
+    for (int step = 0; step < n - 1; ++step) {
+        const int cur = cur_s;
+        if (t <= dim) xnew[t] = (t < dim) ? xs[(size_t)cur * dim + t] : core[cur];
+        __syncthreads();
+        const double ccur = xnew[dim];
+        double mv = inf;
+        int mi = 0x7fffffff;
+        for (int i = t; i < n; i += nt) {
+            double b = best[i];
+            if (b >= 0.0) {
+                double d2 = 0.0;
+#pragma unroll
+                for (int d = 0; d < KB_SIL_MAXDIM; ++d)
+                    if (d < dim) { const double df = xs[(size_t)i * dim + d] - xnew[d]; d2 = fma(df, df, d2); }
+                double w = sqrt(d2);
+                w = fmax(w, fmax(core[i], ccur));
+                if (w < b) { b = w; best[i] = w; src[i] = cur; }
+                if (b < mv) { mv = b; mi = i; }
+            }
+        }
+        // workgroup argmin, ties -> lowest index
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(mv, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
+            if (ov < mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; }
+        }
+        if ((t & 63) == 0) { red_v[t >> 6] = mv; red_i[t >> 6] = mi; }
+        __syncthreads();
+        if (t == 0) {
+            double bv = red_v[0];
+            int bi = red_i[0];
+            for (int wv = 1; wv < (nt >> 6); ++wv)
+                if (red_v[wv] < bv || (red_v[wv] == bv && red_i[wv] < bi)) { bv = red_v[wv]; bi = red_i[wv]; }
+            edges[step] = KbEdge{src[bi], bi, bv};
+            best[bi] = -1.0;
+            cur_s = bi;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace kb

@@ -200,6 +200,18 @@ class Engine:
                                                     _lib.ptr(out)))
         return out
 
+    def hdbscan_sweep(self, X, min_samples_list, min_cluster_size=5):
+        """HDBSCAN* labels for every `min_samples` of the list in one GPU call (the clustering sweep of
+        llckbdm.py:104-110): one pass of k-nearest-neighbour distances shared by all fits, one Prim MST per fit
+        (all fits concurrently), condensed trees on host threads.  Returns (labels[nfits, n], nclusters[nfits])."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        ms = np.ascontiguousarray(min_samples_list, dtype=np.int32)
+        labels = np.empty((len(ms), X.shape[0]), dtype=np.int32)
+        ncl = np.empty(len(ms), dtype=np.int32)
+        _lib.check(self.lib.kbdm_hdbscan_sweep(self.ctx, _lib.ptr(X), X.shape[0], X.shape[1], _lib.ptr(ms), len(ms),
+                                               int(min_cluster_size), _lib.ptr(labels), _lib.ptr(ncl)))
+        return labels, ncl
+
     def eig(self, mats):
         n = np.array([a.shape[0] for a in mats], dtype=np.int32)
         flat = np.concatenate([np.ascontiguousarray(a, dtype=np.complex128).ravel() for a in mats])

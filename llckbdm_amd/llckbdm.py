@@ -3,10 +3,12 @@ batched), pool and filter the lines, sweep `min_samples` of a density clusterer 
 (Re mu, Im mu, A, 0) feature space, summarise every clustering into one line list, keep the one with the
 smallest frequency-domain RMSE (GPU, one call for all candidates).
 
-What runs where: the ensemble, the RMSE scoring and the silhouettes are HIP kernels; the feature transform and
-the cluster summaries are O(n) numpy; the density clustering itself is the reference's third-party dependency
-(`hdbscan.HDBSCAN`, llckbdm.py:280) - used when importable, else scikit-learn's HDBSCAN (same algorithm family;
-cluster labels are not pinned by the reference)."""
+What runs where: the ensemble, the RMSE scoring, the silhouettes and the density clustering (HDBSCAN*, every value of
+`min_samples` of the sweep in ONE call: `Engine.hdbscan_sweep`) are HIP kernels plus host tree code in the C-ABI
+library; the feature transform and the cluster summaries are O(n) numpy.  The reference's clusterer is the
+third-party `hdbscan.HDBSCAN` (llckbdm.py:280), unpinned upstream and absent here; cluster labels are not pinned by
+the reference.  `clusterer="hdbscan"` / `"sklearn"` select those packages instead of the built-in
+one (they cost seconds per fit at the pooled-line counts of a C2 ensemble)."""
 import logging
 
 import attr
@@ -46,18 +48,26 @@ class ClusteringResult:
     clustered_silhouettes: np.ndarray = np.array([])
 
 
-def _make_clusterer(min_samples):
-    """The reference's `hdbscan.HDBSCAN(min_samples=...)` (llckbdm.py:280) when that package is installed,
-    otherwise scikit-learn's implementation with the same defaults (min_cluster_size=5)."""
-    try:
+MIN_CLUSTER_SIZE = 5        # hdbscan.HDBSCAN's default, which the reference does not change (llckbdm.py:280)
+
+
+def _fit_labels(transformed_samples, min_samples, clusterer, engine):
+    """Cluster labels of one HDBSCAN fit.  "gpu": the built-in implementation; "hdbscan": the reference's package
+    (llckbdm.py:280) if installed; "sklearn": scikit-learn's HDBSCAN."""
+    if clusterer == "gpu":
+        eng = engine or default_engine()
+        return eng.hdbscan_sweep(transformed_samples, [min_samples], MIN_CLUSTER_SIZE)[0][0]
+    if clusterer == "hdbscan":
         import hdbscan
-        return hdbscan.HDBSCAN(min_samples=min_samples)
-    except ImportError:
+        return np.asarray(hdbscan.HDBSCAN(min_samples=min_samples).fit(transformed_samples).labels_)
+    if clusterer == "sklearn":
         from sklearn.cluster import HDBSCAN
-        return HDBSCAN(min_samples=min_samples, min_cluster_size=5, copy=True)
+        return np.asarray(HDBSCAN(min_samples=min_samples, min_cluster_size=MIN_CLUSTER_SIZE, copy=True)
+                          .fit(transformed_samples).labels_)
+    raise ValueError("clusterer must be 'gpu', 'hdbscan' or 'sklearn'")
 
 
-def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None):
+def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None, clusterer="gpu"):
     """Line List Clustering KBDM.  Reference: llckbdm.py:41-141 (same arguments, result type and error)."""
     if len(m_range) < 2:
         raise ValueError("size of 'm_range' must be greater than 2.")
@@ -70,10 +80,21 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None):
     transformed_line_list = _transform_line_lists(samples, dwell)
     m_range_size = len(m_range)
     clustering_results = []
-    for min_samples in range(int(np.ceil(0. * m_range_size + 1)), m_range_size):     # llckbdm.py:104
+    sweep = list(range(int(np.ceil(0. * m_range_size + 1)), m_range_size))           # llckbdm.py:104
+    # min_samples cannot exceed the number of pooled lines (the packages raise there; such fits have no clusters)
+    labels_all = None
+    if clusterer == "gpu" and len(transformed_line_list) >= 2:
+        fits = [k for k in sweep if k <= len(transformed_line_list)]
+        if fits:
+            got, _ = eng.hdbscan_sweep(transformed_line_list, fits, MIN_CLUSTER_SIZE)
+            labels_all = dict(zip(fits, got))
+    for min_samples in sweep:
         logger.debug('HDBSCAN with min_samples = %d', min_samples)
+        if clusterer == "gpu" and (labels_all is None or min_samples not in labels_all):
+            continue
         clustering_result = _cluster_line_lists(samples=samples, transformed_samples=transformed_line_list,
-                                                min_samples=min_samples, engine=eng)
+                                                min_samples=min_samples, engine=eng, clusterer=clusterer,
+                                                labels=None if labels_all is None else labels_all[min_samples])
         if clustering_result.num_clusters > 0:
             clustering_results.append(clustering_result)
     summarized_line_lists = [cl_result.summarized_line_list for cl_result in clustering_results]
@@ -86,7 +107,7 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None):
 
 
 def iterative_llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, max_iterations=5, silhouette_threshold=0.6,
-                       engine=None):
+                       engine=None, clusterer="gpu"):
     """Residual peeling driver.  Reference: llckbdm.py:144-199."""
     if max_iterations < 1:
         raise ValueError("'max_iterations must be greater than zero")
@@ -101,7 +122,7 @@ def iterative_llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, max_iterations=
     for i in range(max_iterations):
         logger.info('Iteration #%d', i)
         curr_res = data - curr_data_est
-        results = llc_kbdm(data=curr_res, dwell=dwell, m_range=m_range, p=p, l=l, q=q, engine=eng)
+        results = llc_kbdm(data=curr_res, dwell=dwell, m_range=m_range, p=p, l=l, q=q, engine=eng, clusterer=clusterer)
         if len(results.line_list) == 0:
             logger.info('No more peaks can be fitted. Stopping.')
             break
@@ -148,14 +169,14 @@ def _inverse_transform_line_lists(transformed_line_lists, dwell):
     return np.column_stack((A, T2, F, PH))
 
 
-def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None):
+def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, clusterer="gpu", labels=None):
     """One density clustering of the pooled lines + per-cluster mean silhouettes + summarised line list.
     Reference: llckbdm.py:264-321.  The silhouettes come from the GPU kernel (`Engine.silhouette_samples`);
     like `sklearn.metrics.silhouette_samples` they are undefined for fewer than 2 or more than n-1 label
     values - the reference would raise there, here such a clustering is reported as having no clusters."""
-    cl_model = _make_clusterer(min_samples)
-    cl_model.fit(transformed_samples)
-    labels = np.asarray(cl_model.labels_)
+    if labels is None:
+        labels = _fit_labels(transformed_samples, min_samples, clusterer, engine)
+    labels = np.asarray(labels)
     num_clusters = len(set(labels.tolist()) - {-1})
     n_labels = len(set(labels.tolist()))
     clustered = []

@@ -30,3 +30,9 @@ class OracleEngine:
 
     def silhouette_samples(self, X, labels):
         return L.silhouette_samples_direct(X, labels)
+
+    def hdbscan_sweep(self, X, min_samples_list, min_cluster_size=5):
+        from sklearn.cluster import HDBSCAN
+        labels = np.array([HDBSCAN(min_samples=int(k), min_cluster_size=min_cluster_size, copy=True).fit(X).labels_
+                           for k in min_samples_list], dtype=np.int32)
+        return labels, np.array([len(set(row.tolist()) - {-1}) for row in labels], dtype=np.int32)

@@ -104,3 +104,40 @@ def test_llc_kbdm_host_logic(gnext):
     est = L.multi_fid(np.arange(len(sig)) * DWELL, line_list)
     assert np.std(est.real - sig.real) < 1e-3 and np.std(est.imag - sig.imag) < 1e-3
     assert len(results.silhouette) == len(results.line_list) and results.rmse < 1e-6
+
+
+def test_hdbscan_tree_part_against_sklearn():
+    """The host half of the built-in HDBSCAN* (C ABI kbdm_hdbscan_labels_from_mst, no GPU needed): fed with a
+    numpy Prim MST of the mutual-reachability graph it reproduces scikit-learn's partitions (same number of
+    clusters; the same samples but for a few on mutual-reachability ties)."""
+    from sklearn.cluster import HDBSCAN
+    from sklearn.metrics import adjusted_rand_score
+    from llckbdm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    c = rng.standard_normal((6, 4)) * 3
+    lab = rng.integers(0, 6, 400)
+    X = np.concatenate([c[lab] + 0.1 * rng.standard_normal((400, 4)), rng.uniform(-8, 8, (60, 4))])
+    n = len(X)
+    D = np.sqrt(((X[:, None, :] - X[None, :, :]) ** 2).sum(-1))
+    for k in (1, 3, 10, 40):
+        core = np.sort(D, axis=1)[:, k - 1]
+        M = np.maximum(np.maximum(core[:, None], core[None, :]), D)
+        intree = np.zeros(n, bool)
+        intree[0] = True
+        best, src = M[0].copy(), np.zeros(n, int)
+        a, b, w = [], [], []
+        for _ in range(n - 1):
+            cand = np.where(intree, np.inf, best)
+            j = int(np.argmin(cand))
+            a.append(src[j]); b.append(j); w.append(cand[j])
+            intree[j] = True
+            upd = (M[j] < best) & ~intree
+            src[upd] = j
+            best = np.minimum(best, M[j])
+        a, b, w = np.array(a, np.int32), np.array(b, np.int32), np.array(w)
+        out = np.zeros(n, np.int32)
+        ncl = lib.kbdm_hdbscan_labels_from_mst(n, _lib.ptr(a), _lib.ptr(b), _lib.ptr(w), 5, _lib.ptr(out))
+        ref = HDBSCAN(min_samples=k, min_cluster_size=5, copy=True).fit(X).labels_
+        assert ncl == len(set(ref.tolist()) - {-1})
+        assert adjusted_rand_score(ref, out) >= 0.99

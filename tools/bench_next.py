@@ -51,3 +51,19 @@ cpu_s = time.perf_counter() - t0
 print(json.dumps({"kernel": "k_silhouette", "n": n, "dim": 4, "classes": 31, "gpu_ms_incl_transfers": 1e3 * gpu_s,
                   "gpu_pairs_per_s": n * n / gpu_s, "cpu_sklearn_ms": 1e3 * cpu_s,
                   "max_abs_diff_vs_sklearn": float(np.abs(s_gpu - s_cpu).max())}))
+
+# ---- HDBSCAN sweep: the 150 fits of one llc_kbdm call on the pooled lines of a C2 ensemble
+ks = list(range(1, 151))
+eng.hdbscan_sweep(X[:2000], ks[:4])
+t0 = time.perf_counter()
+labels, ncl = eng.hdbscan_sweep(X, ks)
+gpu_s = time.perf_counter() - t0
+from sklearn.cluster import HDBSCAN  # noqa: E402
+from sklearn.metrics import adjusted_rand_score  # noqa: E402
+t0 = time.perf_counter()
+refs = {k: HDBSCAN(min_samples=k, min_cluster_size=5, copy=True).fit(X).labels_ for k in (1, 50, 150)}
+cpu_s = (time.perf_counter() - t0) / 3 * len(ks)
+print(json.dumps({"kernel": "k_knn_dist + k_prim_mst + host trees", "n": n, "fits": len(ks), "gpu_s_incl_transfers": gpu_s,
+                  "cpu_sklearn_s_extrapolated": cpu_s,
+                  "clusters_gpu_vs_sklearn": {str(k): [int(ncl[k - 1]), len(set(refs[k].tolist()) - {-1})] for k in refs},
+                  "ari_vs_sklearn": {str(k): float(adjusted_rand_score(refs[k], labels[k - 1])) for k in refs}}))
