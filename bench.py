@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2, help="ensembles (steps) in flight at once")
     ap.add_argument("--workload", default="C2", choices=["C2", "C3small"])
     args = ap.parse_args()
 
@@ -121,16 +122,27 @@ def main():
     from llckbdm_amd import datasets
     from llckbdm_amd.engine import Engine
 
-    eng = Engine(local_rank)
+    # Ensembles in flight: every step solves one whole ensemble (its own plan, workspace and streams); a step
+    # is submitted without waiting for the previous one, and a plan is waited for only when its workspace is
+    # needed again.  One ensemble alone is latency bound (a chain of one-CU-per-member kernels, most of the
+    # 256 CUs idle); two in flight overlap those chains.  `step_latency_ms` is the single-ensemble latency.
+    nfl = max(1, args.in_flight)
     dwell = datasets.DWELL
-    if args.workload == "C2":
-        sigs, sig_idx, ms = datasets.config2(seed=rank)
-        wname = "C2: N=2048, 16 peaks + sigma=1e-3 noise, m=100..400:2 (151 members), l=m, p=1, q=0"
-    else:
-        sigs, sig_idx, ms = datasets.config3(count=64, m=512, seed0=1000 * rank)
-        wname = "C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512"
-    plan = eng.plan(sigs.shape[0], sigs.shape[1], sig_idx, ms, ms, p=1, q=0.0, dwell=dwell)
-    plan.upload(sigs)
+    engines, plans = [], []
+    for k in range(nfl):
+        if args.workload == "C2":
+            sigs, sig_idx, ms = datasets.config2(seed=rank + 1000 * k)
+            wname = "C2: N=2048, 16 peaks + sigma=1e-3 noise, m=100..400:2 (151 members), l=m, p=1, q=0"
+        else:
+            sigs, sig_idx, ms = datasets.config3(count=64, m=512, seed0=1000 * rank + 100000 * k)
+            wname = "C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512"
+        e = Engine(local_rank)
+        pk = e.plan(sigs.shape[0], sigs.shape[1], sig_idx, ms, ms, p=1, q=0.0, dwell=dwell)
+        pk.upload(sigs)
+        engines.append(e)
+        plans.append(pk)
+    plan = plans[0]
+    sigs0 = datasets.config2(seed=rank)[0] if args.workload == "C2" else None
     units = len(ms)
 
     gather_buf = local_buf = None
@@ -139,31 +151,60 @@ def main():
         gather_buf = torch.empty((world * plan.total_lines, 4), dtype=torch.float64, device="cuda")
 
     def sync_all():
-        plan.sync()
+        for pk in plans:
+            pk.sync()
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
 
-    def step():
-        plan.execute(sync=False)
-        if dist is not None:
-            plan.copy_lines_to_device(local_buf.data_ptr(), local_buf.numel() * 8)   # syncs the plan stream
-            dist.all_gather_into_tensor(gather_buf, local_buf)
+    stage_acc = {}
+    busy = [False] * nfl
+    timed = [False]
 
-    for _ in range(args.warmup):
-        step()
+    def finish(k):
+        """Complete the step that plan k is running: wait, (multi-process) gather its line lists, stage timers."""
+        if not busy[k]:
+            return
+        pk = plans[k]
+        if dist is not None:
+            pk.copy_lines_to_device(local_buf.data_ptr(), local_buf.numel() * 8)   # syncs the plan's stream
+            dist.all_gather_into_tensor(gather_buf, local_buf)
+        if timed[0]:
+            for name, v in pk.stage_ms().items():      # HIP events of the critical lane (waits for the plan)
+                stage_acc[name] = stage_acc.get(name, 0.0) + v
+        else:
+            pk.sync()
+        busy[k] = False
+
+    def step(s):
+        k = s % nfl
+        finish(k)
+        plans[k].execute(sync=False)
+        busy[k] = True
+
+    # warm-up: one ensemble at a time, which also gives the single-ensemble latency
+    latency = None
+    for s in range(args.warmup):
+        sync_all()
+        tw = time.perf_counter()
+        step(s)
+        finish(s % nfl)
+        sync_all()
+        tw = time.perf_counter() - tw
+        latency = tw if latency is None else min(latency, tw)
+    for k in range(nfl):               # every plan has run once before the timed region
+        if args.warmup <= k:
+            step(k)
+            finish(k)
     sync_all()
     if dist is not None:
         dist.barrier()
     sync_all()
-    stage_acc = {}
+    timed[0] = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if dist is None:
-            # per-stage HIP-event times (waits for the stream; the next step could not overlap anyway:
-            # it reuses the same workspace)
-            for k, v in plan.stage_ms().items():
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
+    for s in range(args.steps):
+        step(s)
+    for s in range(args.steps, args.steps + nfl):     # drain in submission order
+        finish(s % nfl)
     sync_all()
     if dist is not None:
         dist.barrier()
@@ -173,11 +214,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        for k, v in plan.stage_ms().items():
-            stage_acc[k] = v * args.steps
 
     res = plan.download()
-    ok = int((res.status == 0).sum())
+    ok = min(int((pk.download().status == 0).sum()) for pk in plans)
 
     if rank == 0:
         value = world * units * args.steps / elapsed
@@ -217,15 +256,17 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
             "config": {"workload": wname, "members_per_gpu": units, "parallelism": f"ensemble-sharded x{world}",
+                       "ensembles_in_flight": nfl,
                        "collective": "one all_gather of packed line lists (RCCL)" if world > 1 else "none"},
             "roofline": roofline,
             "pipeline_tflops": total_fl * args.steps * world / elapsed / 1e12,
             "stage_ms": stage_ms,
+            "step_latency_ms": None if latency is None else 1e3 * latency,
             "members_ok": ok,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(sigs[0], ms, dwell) if args.workload == "C2" else None
+                out["cpu_baseline"] = cpu_baseline(sigs0[0], ms, dwell) if args.workload == "C2" else None
             except Exception as e:   # the baseline is informational; never lose the GPU number over it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
