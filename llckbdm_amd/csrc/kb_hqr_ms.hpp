@@ -68,6 +68,7 @@ struct MsStats {          // optional instrumentation (host simulation / KBDM_HQ
     long long intervals, batches, single_sweeps, small_steps;
     long long cyc_scan, cyc_shift, cyc_load, cyc_chase, cyc_store, cyc_strip, cyc_single, cyc_total;
     long long cyc_tload, cyc_treplay, cyc_tstore, ntiles;
+    long long ab_calls, ab_fail, ab_iters;   // Aberth shift solves / fallbacks to the QR solver / iterations (ns = 8)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -899,9 +900,215 @@ KB_HD void chase_windowed(const C& ctx, const ACC& A, int l, int i, int ns, cons
 #undef HW
 }
 
+// All eigenvalues of a small unreduced upper Hessenberg matrix T (n <= wavefront size) by simultaneous
+// Ehrlich-Aberth iteration on the characteristic polynomial, ONE LANE PER ROOT: p(z) and p'(z) come from
+// Hyman's recurrence (the left null-vector recurrence of T - z I, O(n^2) per root and evaluation, backward
+// stable for Hessenberg matrices), roots start at the diagonal.  Where the one-wavefront QR iteration
+// (hqr_eigvals) is a chain of ~3 n^2 dependent rotation steps, this is a handful of iterations that all lanes
+// take in parallel: the shift computation of the multishift iteration drops from ~140 k to ~20 k cycles.
+// The roots are accurate to a few ulp of |z| (they are used as shifts: a shift error of 1e-6 already costs
+// half as many sweeps again).  Returns false (caller falls back to hqr_eigvals) on a zero subdiagonal, a
+// non-finite value or no convergence within maxit iterations.
+//   wc: wavefront context; T column-major (ldt), read only; z: n roots out (LDS);
+//   U, D: n*n each (LDS; recurrence vectors, [i * n + root]);  zw: 2 n (LDS).
+template <class WC>
+KB_HD bool aberth_eigs(const WC& wc, int n, const cd* T, int ldt, cd* z, cd* U, cd* D, cd* zw, int maxit) {
+#define TT(i_, j_) T[(i_) + (j_) * ldt]
+    const int lane = wc.lane();
+    constexpr int WS = WC::WS;
+    cd* rinv = zw + n;
+    double sc = 0.0;
+    int bad = 0;
+    for (int idx = lane; idx < n * n; idx += WS) {
+        const int r = idx % n, c = idx / n;
+        if (r <= c + 1) sc = fmax(sc, cabs1(TT(r, c)));
+    }
+    sc = wc.wave_max(sc);
+    for (int r = lane; r < n; r += WS) {
+        z[r] = TT(r, r);
+        if (r < n - 1) {
+            const cd h = TT(r + 1, r);
+            if (is_zero(h)) bad = 1;
+            else rinv[r] = cdiv(mk(1.0, 0.0), h);
+        }
+    }
+    wc.sync();
+    // coincident starting points would divide by zero in the Aberth sum: spread them
+    for (int r = lane; r < n; r += WS) {
+        cd zr = z[r];
+        for (int k = 0; k < r; ++k)
+            if (cabs1(zr - z[k]) <= 1e-8 * sc) {
+                const double a = 1e-4 * sc * (double)(r + 1);
+                zr = zr + mk(a * (1.0 - 0.125 * k), a * 0.0625 * (k + 1));
+            }
+        zw[r] = zr;
+    }
+    wc.sync();
+    for (int r = lane; r < n; r += WS) { z[r] = zw[r]; zw[r] = czero(); }   // zw[r].x becomes the "converged" flag
+    wc.sync();
+    if (wc.wave_max(bad) != 0 || !(sc > 0.0)) return false;
+    bool conv_all = false;
+    for (int it = 0; it < maxit && !conv_all; ++it) {
+        int open_ = 0;
+        for (int r = lane; r < n; r += WS) {
+            const cd zr = z[r];
+            // Hyman: u_0 = 1; u_{j+1} = -(sum_{i<=j} u_i T(i,j) - z u_j) / T(j+1,j); p = the last sum
+            cd* u = U + r;
+            cd* d = D + r;
+            u[0] = mk(1.0, 0.0);
+            d[0] = czero();
+            cd acc = czero(), dacc = czero();
+            for (int j = 0; j < n; ++j) {
+                acc = czero();
+                dacc = czero();
+                for (int i = 0; i <= j; ++i) {
+                    const cd t = TT(i, j);
+                    cfma(acc, u[i * n], t);
+                    cfma(dacc, d[i * n], t);
+                }
+                const cd uj = u[j * n], dj = d[j * n];
+                cfma(acc, -zr, uj);
+                cfma(dacc, -zr, dj);
+                dacc = dacc - uj;
+                if (j < n - 1) {
+                    u[(j + 1) * n] = -(acc * rinv[j]);
+                    d[(j + 1) * n] = -(dacc * rinv[j]);
+                }
+            }
+            cd dz = czero();
+            const bool frozen = zw[r].x != 0.0;         // zw[r].x: 1 once the root has converged
+            if (!frozen) {
+                if (is_zero(acc)) dz = czero();
+                else {
+                    const cd nw = cdiv(acc, dacc);       // Newton correction p / p'
+                    cd sum = czero();
+                    for (int k = 0; k < n; ++k)
+                        if (k != r) sum = sum + cdiv(mk(1.0, 0.0), zr - z[k]);
+                    dz = cdiv(nw, mk(1.0, 0.0) - nw * sum);
+                }
+                if (!(cabs1(dz) < 1e300)) { bad = 1; dz = czero(); }
+                if (cabs1(dz) <= 4.0 * KB_ULP * fmax(cabs1(zr), 0.015625 * sc)) zw[r].x = 1.0;
+                else open_ = 1;
+            }
+            zw[r].y = 0.0;
+            U[r] = zr - dz;                              // u_0 slot reused as the new root (rewritten next pass)
+        }
+        wc.sync();
+        for (int r = lane; r < n; r += WS) z[r] = U[r];
+        wc.sync();
+        conv_all = wc.wave_max(open_) == 0;
+        if (wc.wave_max(bad) != 0) return false;
+    }
+    return conv_all;
+#undef TT
+}
+
+// The same iteration for exactly NR roots with the recurrence vectors in registers (fully unrolled: static
+// indices), T read through LDS broadcasts only - the common case of the multishift iteration (ns = NR = 8).
+// 1 / (z_r - z_k) is formed as conj / |.|^2 (the differences of distinct roots of a matrix of norm ~sc are far
+// from the under/overflow thresholds; a non-finite value ends in the fallback like everything else).
+template <int NR, class WC>
+KB_HD bool aberth_eigs_reg(const WC& wc, const cd* __restrict__ T, int ldt, cd* z, cd* zw, int maxit, int* iters) {
+#define TT(i_, j_) T[(i_) + (j_) * ldt]
+    const int lane = wc.lane();
+    constexpr int WS = WC::WS;
+    constexpr int n = NR;
+    cd* rinv = zw + n;
+    double sc = 0.0;
+    int bad = 0;
+    for (int idx = lane; idx < n * n; idx += WS) {
+        const int r = idx % n, c = idx / n;
+        if (r <= c + 1) sc = fmax(sc, cabs1(TT(r, c)));
+    }
+    sc = wc.wave_max(sc);
+    for (int r = lane; r < n; r += WS) {
+        z[r] = TT(r, r);
+        if (r < n - 1) {
+            const cd h = TT(r + 1, r);
+            if (is_zero(h)) bad = 1;
+            else rinv[r] = cdiv(mk(1.0, 0.0), h);
+        }
+    }
+    wc.sync();
+    for (int r = lane; r < n; r += WS) {
+        cd zr = z[r];
+        for (int k = 0; k < r; ++k)
+            if (cabs1(zr - z[k]) <= 1e-8 * sc) {
+                const double a = 1e-4 * sc * (double)(r + 1);
+                zr = zr + mk(a * (1.0 - 0.125 * k), a * 0.0625 * (k + 1));
+            }
+        zw[r] = zr;
+    }
+    wc.sync();
+    for (int r = lane; r < n; r += WS) { z[r] = zw[r]; zw[r] = czero(); }
+    wc.sync();
+    if (wc.wave_max(bad) != 0 || !(sc > 0.0)) return false;
+    bool conv_all = false;
+    int it = 0;
+    for (; it < maxit && !conv_all; ++it) {
+        int open_ = 0;
+        for (int r = lane; r < n; r += WS) {
+            const cd zr = z[r];
+            cd u[NR], d[NR];
+            u[0] = mk(1.0, 0.0);
+            d[0] = czero();
+            cd acc = czero(), dacc = czero();
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                // two partial sums per recurrence: shorter dependent chains
+                cd a0 = czero(), a1 = czero(), b0 = czero(), b1 = czero();
+#pragma unroll
+                for (int i = 0; i <= j; ++i) {
+                    const cd t = TT(i, j);
+                    if (i & 1) { cfma(a1, u[i], t); cfma(b1, d[i], t); }
+                    else { cfma(a0, u[i], t); cfma(b0, d[i], t); }
+                }
+                acc = a0 + a1;
+                dacc = b0 + b1;
+                cfma(acc, -zr, u[j]);
+                cfma(dacc, -zr, d[j]);
+                dacc = dacc - u[j];
+                if (j < NR - 1) {
+                    const cd ri = rinv[j];
+                    u[j + 1] = -(acc * ri);
+                    d[j + 1] = -(dacc * ri);
+                }
+            }
+            cd dz = czero();
+            const bool frozen = zw[r].x != 0.0;
+            if (!frozen) {
+                if (!is_zero(acc)) {
+                    const cd nw = cdiv(acc, dacc);
+                    cd sum = czero();
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        const cd df = zr - z[k];
+                        const double q = 1.0 / abs2(df);
+                        if (k != r) sum = sum + mk(df.x * q, -df.y * q);
+                    }
+                    dz = cdiv(nw, mk(1.0, 0.0) - nw * sum);
+                }
+                if (!(cabs1(dz) < 1e300)) { bad = 1; dz = czero(); }
+                if (cabs1(dz) <= 4.0 * KB_ULP * fmax(cabs1(zr), 0.015625 * sc)) zw[r].x = 1.0;
+                else open_ = 1;
+            }
+            zw[r].y = 0.0;
+            rinv[n + r] = zr - dz;
+        }
+        wc.sync();
+        for (int r = lane; r < n; r += WS) z[r] = rinv[n + r];
+        wc.sync();
+        conv_all = wc.wave_max(open_) == 0;
+        if (wc.wave_max(bad) != 0) return false;
+    }
+    if (iters) *iters = it;
+    return conv_all;
+#undef TT
+}
+
 template <class C>
 KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, int nsmax,
-                          MsStats* stats = nullptr, int win_w = 0, Team<C>* team = nullptr) {
+                          MsStats* stats = nullptr, int win_w = 0, Team<C>* team = nullptr, bool aberth = true) {
 #define HH(i_, j_) H[(i_) + (size_t)(j_) * ld]
     const double ulp = KB_ULP;
     const double smlnum = KB_SAFMIN * ((double)n / ulp);
@@ -913,6 +1120,8 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
     int* sinfo = reinterpret_cast<int*>(refl + nsmax);
     int fail = 0;
     bool bail = false;
+    // workspace of the Aberth shift solver: the window image, idle between two chases
+    cd* aws = (win_w > 0 && aberth) ? win_lds(ctx, win_w, nsmax).Hw : nullptr;
     if (n == 1) {
         if (tid == 0) { w[0] = HH(0, 0); *info = 0; }
         ctx.sync();
@@ -996,7 +1205,14 @@ KB_HD void hqr_eigvals_ms(const C& ctx, int n, cd* H, int ld, cd* w, int* info, 
                     ctx.sync();
                     if (ctx.wave() == 0) {
                         WaveCtx<C> wc{ctx, nullptr, 0};
-                        hqr_eigvals(wc, ns, S, ns, sh, sinfo);
+                        bool ok = false;
+                        if (aws && ns >= 3 && ns <= C::WS * 64) {
+                            int iters = 0;
+                            if (ns == 8) ok = aberth_eigs_reg<8>(wc, S, ns, sh, aws, 40, &iters);
+                            else ok = aberth_eigs(wc, ns, S, ns, sh, aws, aws + ns * ns, aws + 2 * ns * ns, 40);
+                            if (stats && tid == 0) { stats->ab_calls++; stats->ab_iters += iters; if (!ok) stats->ab_fail++; }
+                        }
+                        if (!ok) hqr_eigvals(wc, ns, S, ns, sh, sinfo);
                     }
                 }
                 ctx.sync();

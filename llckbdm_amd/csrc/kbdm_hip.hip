@@ -60,6 +60,7 @@ struct Lane {
 };
 
 #define KB_MAX_LANES 8
+#define KB_QUEUE_WORDS 64   // work-queue counters behind the per-member words of d_iwork (one per chunk)
 
 struct kbdm_ctx {
     int device = 0;
@@ -79,6 +80,7 @@ struct kbdm_ctx {
     int invit_reg = 1;    // inverse iteration with register-resident vectors for l <= 512 (0: the LDS form)
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
+    int hqr_wgs = 64;     // workgroups of the solo k_hqr launch: members are taken from a queue, largest first
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
 };
@@ -257,7 +259,7 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_mu, sizeof(cd) * std::max<int64_t>(pl->total_lines, 1)));
     HIPCHK(hipMalloc(&pl->d_keep, std::max<int64_t>(pl->total_lines, 1)));
     HIPCHK(hipMalloc(&pl->d_status, sizeof(int) * B));
-    HIPCHK(hipMalloc(&pl->d_iwork, sizeof(int) * 4 * std::max(B, 1)));
+    HIPCHK(hipMalloc(&pl->d_iwork, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
     HIPCHK(hipMalloc(&pl->d_team, sizeof(TeamCtl) * std::max(B, 1)));
     HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS * team_rec_bytes(pl->ctx->ns_hqr, std::max(pl->ctx->win_hqr, 8))));
     HIPCHK(hipMalloc(&pl->d_rot, sizeof(Rot) * std::max<size_t>(pl->rot_elems, 1)));
@@ -432,8 +434,14 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         }
         if (ch.count > nteam) {
             hipStream_t ss = nteam > 0 ? ln.stream2 : st;
-            hipLaunchKernelGGL(k_hqr, dim3(ch.count - nteam), dim3(ctx->nt_hqr), sm, ss, pl->d_items, perm + nteam,
-                               pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof);
+            // a bounded number of workgroups takes the members from a queue (they are sorted by size,
+            // largest first): the launch lasts as long as its largest member either way, and the CUs it
+            // does not occupy go to the other lane's / the next ensemble's throughput-bound stages
+            const int nsolo = ch.count - nteam;
+            const int cidx = (int)(&ch - pl->chunks.data());
+            int* queue = (ctx->hqr_wgs > 0 && nsolo > ctx->hqr_wgs && cidx < KB_QUEUE_WORDS) ? pl->d_iwork + 4 * pl->B + cidx : nullptr;
+            hipLaunchKernelGGL(k_hqr, dim3(queue ? ctx->hqr_wgs : nsolo), dim3(ctx->nt_hqr), sm, ss, pl->d_items, perm + nteam,
+                               pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof, nsolo, queue);
             if (nteam > 0) HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));   // the join now covers Qh and the solo members
         }
         if (do_prof) {   // diagnostic build path only: synchronous dump of the largest item's counters
@@ -581,6 +589,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
     c->invit_reg = env_int("KBDM_INVIT_REG", c->invit_reg);
     c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
+    c->hqr_wgs = std::max(0, env_int("KBDM_HQR_WGS", c->hqr_wgs));
     c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
     if (c->nt_hqr > 512) c->nt_hqr = 512;
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
@@ -656,7 +665,7 @@ int kbdm_plan_execute(kbdm_plan* pl) {
     hipStream_t st = ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemsetAsync(pl->d_status, 0, sizeof(int) * pl->B, st));
-    HIPCHK(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * 4 * pl->B, st));
+    HIPCHK(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * pl->B + KB_QUEUE_WORDS), st));
     HIPCHK(hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * pl->B, st));
     // groups one after the other (they share the arena); inside a group one chunk per lane, all
     // lanes concurrently: fork from the main stream, join back into it
@@ -823,7 +832,7 @@ int kbdm_svd_batch(kbdm_ctx* ctx, const double* A, int B, const int32_t* m, doub
         if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
         hipMemcpy(d_dense, A, sizeof(cd) * tot, hipMemcpyHostToDevice);
         hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
-        hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * 4 * B, st);
+        hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * B + KB_QUEUE_WORDS), st);
         for (auto& ch : pl->chunks) {
             // stage plans are built in one chunk by construction of the tests; handle generally
             hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_A, 0);

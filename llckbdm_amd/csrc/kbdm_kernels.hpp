@@ -98,60 +98,91 @@ __global__ void __launch_bounds__(1024) k_bidiag_panel(const KbItem* __restrict_
     bidiag_panel(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
 }
 
-// Trailing update of one panel:  C[r, c] -= sum_k Aop[r, k] conj(Bop[c, k]),  r, c in [NB, n),
-// Aop = [V | X], Bop = [Y | U], K = 2 NB.  One workgroup = 64 x 64 block of C, each of its four
-// wavefronts a 32 x 32 sub-block as 2 x 2 v_mfma_f64_16x16x4_f64 tiles (real and imaginary
-// accumulators).  The MFMA computes D'[c][r] (output column on the MFMA row index) so that the
-// 16 lanes of a quarter-wave hold 16 consecutive ROWS of C: coalesced 256-byte read-modify-write.
+// Rank-64 update of one 64 x 64 tile of C on FP64 MFMA:  C[r, c] -= sum_k Aop(r, k) conj(Bop(c, k)), k < 2 NB.
+// The operands go through LDS: the workgroup stages them in chunks of 8 k (re and im planes, [k][row], row
+// pitch 80 doubles so that the four k-groups of a wavefront's ds_read_b64 hit disjoint banks), double
+// buffered with the next chunk's global loads in flight under the current chunk's MFMAs; every operand element
+// is fetched from L2 once per workgroup instead of once per wavefront.  Each of the four wavefronts owns a
+// 32 x 32 sub-block as 2 x 2 v_mfma_f64_16x16x4_f64 tiles (real and imaginary accumulators).  The MFMA computes
+// D'[c][r] (output column on the MFMA row index) so that the 16 lanes of a quarter-wave hold 16 consecutive
+// ROWS of C: coalesced 256-byte read-modify-write.
 //   f64 MFMA operand maps (cdna_hip_programming.md 3): A: lane l -> A[l & 15][l >> 4],
 //   B: lane l -> B[l >> 4][l & 15],  C/D: col = l & 15, row = (l >> 4) + 4 * reg.
+//   Aop(r, k), Bop(c, k): accessors with r, c relative to the tile origin (they return 0 outside the matrix).
 typedef double kb_d4 __attribute__((ext_vector_type(4)));
+constexpr int KB_TU_KC = 8;       // k per staged chunk
+constexpr int KB_TU_PITCH = 80;   // doubles per k row in LDS
 
-__global__ void __launch_bounds__(256) k_trail_update(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                       cd* arena, int panel) {
-    const KbItem it = items[perm[blockIdx.z]];
-    const int m = it.m;
-    if (panel >= bidiag_num_panels(m)) return;
-    const int p0 = panel * KB_NB;
-    const int n = m - p0;                        // trailing block size at panel start
-    const int nn = n - KB_NB;                    // updated block is nn x nn at local offset NB
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r0 = blockIdx.x * 64 + (wave & 1) * 32;   // local to the updated block
-    const int c0 = blockIdx.y * 64 + (wave >> 1) * 32;
-    if (blockIdx.x * 64 >= nn || blockIdx.y * 64 >= nn) return;
-    const cd* A = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;    // V in columns 0..NB-1
-    const cd* UR = arena + it.off[KB_BUF_R] + p0 + (size_t)p0 * m;   // U
-    const cd* X = arena + it.off[KB_BUF_Q];
-    const cd* Y = arena + it.off[KB_BUF_P];
-    cd* C = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;
+template <class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
+    __shared__ double s_op[2][2][2][KB_TU_KC][KB_TU_PITCH];   // [buffer][A|B][re|im][k][row]
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lk = lane >> 4;
+    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    const int srow = t & 63, sk = t >> 6;                       // staging: row, k (and k + 4)
     kb_d4 acc_re[2][2], acc_im[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
-    for (int k0 = 0; k0 < 2 * KB_NB; k0 += 4) {
-        const int k = k0 + lk;
-        const bool second = k >= KB_NB;              // uniform per k0 (NB is a multiple of 4)
-        const int kk = second ? k - KB_NB : k;
-        cd av[2], bv[2];
+    constexpr int NCH = 2 * KB_NB / KB_TU_KC;
+    // the C tile is fetched up front: its latency hides under the whole k loop
+    cd cv[2][2][4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int r = KB_NB + r0 + a * 16 + li;  // row of C (local to the trailing block)
-            const int c = KB_NB + c0 + a * 16 + li;  // column of C
-            av[a] = (r < n) ? (second ? X[r + (size_t)kk * m] : A[r + (size_t)kk * m]) : czero();
-            bv[a] = (c < n) ? (second ? UR[c + (size_t)kk * m] : Y[c + (size_t)kk * m]) : czero();
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const cd* pc = Cptr(wr + rb * 16 + li, wc + cb * 16 + lk + 4 * g);
+                cv[cb][rb][g] = pc ? *pc : czero();
+            }
+    cd ga[2], gb[2];
+    ga[0] = Aop(srow, sk); ga[1] = Aop(srow, sk + 4);
+    gb[0] = Bop(srow, sk); gb[1] = Bop(srow, sk + 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        s_op[0][0][0][sk + 4 * j][srow] = ga[j].x; s_op[0][0][1][sk + 4 * j][srow] = ga[j].y;
+        s_op[0][1][0][sk + 4 * j][srow] = gb[j].x; s_op[0][1][1][sk + 4 * j][srow] = gb[j].y;
+    }
+    __syncthreads();
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < NCH) {
+            const int kn = (ch + 1) * KB_TU_KC + sk;
+            ga[0] = Aop(srow, kn); ga[1] = Aop(srow, kn + 4);
+            gb[0] = Bop(srow, kn); gb[1] = Bop(srow, kn + 4);
         }
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int ks = 0; ks < KB_TU_KC; ks += 4) {
+            double ar[2], ai[2], br[2], bi[2];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                // D'[c][r] += Bop(c,k) (MFMA A operand) * Aop(r,k) (MFMA B operand), complex with conj(Bop)
-                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].x, acc_re[cb][rb], 0, 0, 0);
-                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].y, av[rb].y, acc_re[cb][rb], 0, 0, 0);
-                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].y, acc_im[cb][rb], 0, 0, 0);
-                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bv[cb].y, av[rb].x, acc_im[cb][rb], 0, 0, 0);
+            for (int a = 0; a < 2; ++a) {
+                ar[a] = s_op[buf][0][0][ks + lk][wr + a * 16 + li];
+                ai[a] = s_op[buf][0][1][ks + lk][wr + a * 16 + li];
+                br[a] = s_op[buf][1][0][ks + lk][wc + a * 16 + li];
+                bi[a] = s_op[buf][1][1][ks + lk][wc + a * 16 + li];
             }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    // D'[c][r] += Bop(c,k) (MFMA A operand) * Aop(r,k) (MFMA B operand), complex with conj(Bop)
+                    acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[cb], ar[rb], acc_re[cb][rb], 0, 0, 0);
+                    acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[cb], ai[rb], acc_re[cb][rb], 0, 0, 0);
+                    acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[cb], ai[rb], acc_im[cb][rb], 0, 0, 0);
+                    acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi[cb], ar[rb], acc_im[cb][rb], 0, 0, 0);
+                }
+        }
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s_op[buf ^ 1][0][0][sk + 4 * j][srow] = ga[j].x; s_op[buf ^ 1][0][1][sk + 4 * j][srow] = ga[j].y;
+                s_op[buf ^ 1][1][0][sk + 4 * j][srow] = gb[j].x; s_op[buf ^ 1][1][1][sk + 4 * j][srow] = gb[j].y;
+            }
+        }
+        __syncthreads();
     }
     // D' element (MFMA row = C column offset, MFMA col = C row offset): col = li, row = lk + 4*reg
 #pragma unroll
@@ -160,16 +191,49 @@ __global__ void __launch_bounds__(256) k_trail_update(const KbItem* __restrict__
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int r = KB_NB + r0 + rb * 16 + li;
-                const int c = KB_NB + c0 + cb * 16 + lk + 4 * g;
-                if (r < n && c < n) {
-                    cd* pc = &C[r + (size_t)c * m];
-                    cd v = *pc;
+                cd* pc = Cptr(wr + rb * 16 + li, wc + cb * 16 + lk + 4 * g);
+                if (pc) {
+                    cd v = cv[cb][rb][g];
                     v.x -= acc_re[cb][rb][g];
                     v.y -= acc_im[cb][rb][g];
                     *pc = v;
                 }
             }
+}
+
+// Trailing update of one panel:  C[r, c] -= sum_k Aop[r, k] conj(Bop[c, k]),  r, c in [NB, n),
+// Aop = [V | X], Bop = [Y | U], K = 2 NB.  One workgroup = 64 x 64 block of C (mfma_rank2nb_tile).
+__global__ void __launch_bounds__(256) k_trail_update(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                       cd* arena, int panel) {
+    const KbItem it = items[perm[blockIdx.z]];
+    const int m = it.m;
+    if (panel >= bidiag_num_panels(m)) return;
+    const int p0 = panel * KB_NB;
+    const int n = m - p0;                        // trailing block size at panel start
+    const int nn = n - KB_NB;                    // updated block is nn x nn at local offset NB
+    if (blockIdx.x * 64 >= nn || blockIdx.y * 64 >= nn) return;
+    const int r0 = KB_NB + blockIdx.x * 64;      // tile origin, local to the trailing block
+    const int c0 = KB_NB + blockIdx.y * 64;
+    const cd* A = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;    // V in columns 0..NB-1
+    const cd* UR = arena + it.off[KB_BUF_R] + p0 + (size_t)p0 * m;   // U
+    const cd* X = arena + it.off[KB_BUF_Q];
+    const cd* Y = arena + it.off[KB_BUF_P];
+    cd* C = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;
+    mfma_rank2nb_tile(
+        [&](int i, int k) -> cd {
+            const int r = r0 + i;
+            if (r >= n) return czero();
+            return (k >= KB_NB) ? X[r + (size_t)(k - KB_NB) * m] : A[r + (size_t)k * m];
+        },
+        [&](int i, int k) -> cd {
+            const int c = c0 + i;
+            if (c >= n) return czero();
+            return (k >= KB_NB) ? UR[c + (size_t)(k - KB_NB) * m] : Y[c + (size_t)k * m];
+        },
+        [&](int i, int jx) -> cd* {
+            const int r = r0 + i, c = c0 + jx;
+            return (r < n && c < n) ? &C[r + (size_t)c * m] : nullptr;
+        });
 }
 
 // One workgroup per item: the remaining columns, unblocked.
@@ -450,58 +514,28 @@ __global__ void __launch_bounds__(256) k_hess_update(const KbItem* __restrict__ 
     const int p0 = panel * KB_NB;
     const int cbase = p0 + KB_NB;                 // first updated column
     const int ncol = n - cbase;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (blockIdx.x * 64 >= n || blockIdx.y * 64 >= ncol) return;
-    const int r0 = blockIdx.x * 64 + (wave & 1) * 32;            // global row
-    const int c0 = cbase + blockIdx.y * 64 + (wave >> 1) * 32;   // global column
+    const int r0 = blockIdx.x * 64;                       // global row of the tile origin
+    const int c0 = cbase + blockIdx.y * 64;               // global column
     cd* W = arena + it.off[KB_BUF_P];
     const cd* Y = arena + it.off[KB_BUF_Q];
     const cd* Z = arena + it.off[KB_BUF_H];
-    const int li = lane & 15, lk = lane >> 4;
-    kb_d4 acc_re[2][2], acc_im[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
-    for (int k0 = 0; k0 < 2 * KB_NB; k0 += 4) {
-        const int k = k0 + lk;
-        const bool second = k >= KB_NB;
-        const int kk = second ? k - KB_NB : k;
-        cd av[2], bv[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int r = r0 + a * 16 + li;
-            const int c = c0 + a * 16 + li;
-            // Aop = [Y | V],  Bop = [V | Z]
-            av[a] = (r < n) ? (second ? hess_vt(W, n, p0, r, kk) : Y[r + (size_t)kk * n]) : czero();
-            bv[a] = (c < n) ? (second ? Z[c + (size_t)kk * n] : hess_vt(W, n, p0, c, kk)) : czero();
-        }
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].x, acc_re[cb][rb], 0, 0, 0);
-                acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].y, av[rb].y, acc_re[cb][rb], 0, 0, 0);
-                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[cb].x, av[rb].y, acc_im[cb][rb], 0, 0, 0);
-                acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bv[cb].y, av[rb].x, acc_im[cb][rb], 0, 0, 0);
-            }
-    }
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = r0 + rb * 16 + li;
-                const int c = c0 + cb * 16 + lk + 4 * g;
-                if (r < n && c < n) {
-                    cd* pc = &W[r + (size_t)c * n];
-                    cd v = *pc;
-                    v.x -= acc_re[cb][rb][g];
-                    v.y -= acc_im[cb][rb][g];
-                    *pc = v;
-                }
-            }
+    // Aop = [Y | V],  Bop = [V | Z]
+    mfma_rank2nb_tile(
+        [&](int i, int k) -> cd {
+            const int r = r0 + i;
+            if (r >= n) return czero();
+            return (k >= KB_NB) ? hess_vt(W, n, p0, r, k - KB_NB) : Y[r + (size_t)k * n];
+        },
+        [&](int i, int k) -> cd {
+            const int c = c0 + i;
+            if (c >= n) return czero();
+            return (k >= KB_NB) ? Z[c + (size_t)(k - KB_NB) * n] : hess_vt(W, n, p0, c, k);
+        },
+        [&](int i, int jx) -> cd* {
+            const int r = r0 + i, c = c0 + jx;
+            return (r < n && c < n) ? &W[r + (size_t)c * n] : nullptr;
+        });
 }
 
 __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items, const int* __restrict__ perm,
@@ -528,15 +562,31 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
 
 __global__ void __launch_bounds__(512) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                cd* arena, double* varena, cd* mu_out, int* status,
-                                               int smem_bytes, int nsmax, int win_w, MsStats* prof) {
-    const int item = perm[blockIdx.x];
-    const KbItem it = items[item];
+                                               int smem_bytes, int nsmax, int win_w, MsStats* prof, int count,
+                                               int* queue) {
+    // queue == nullptr: workgroup b solves member perm[b].  Otherwise the workgroups of the launch take
+    // members perm[0], perm[1], ... (largest first) from the queue until it is empty.
     const DevCtx ctx = make_ctx(smem_bytes);
-    cd* Hc = arena + it.off[KB_BUF_H];
-    cd* mu = mu_out + it.line_off;
     __shared__ int info;
-    hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, prof ? prof + item : nullptr, win_w);
-    if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
+    __shared__ int next;
+    for (;;) {
+        int idx = blockIdx.x;
+        if (queue) {
+            if (threadIdx.x == 0) next = atomicAdd(queue, 1);
+            __syncthreads();
+            idx = next;
+            __syncthreads();
+        }
+        if (idx >= count) break;
+        const int item = perm[idx];
+        const KbItem it = items[item];
+        cd* Hc = arena + it.off[KB_BUF_H];
+        cd* mu = mu_out + it.line_off;
+        hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, prof ? prof + item : nullptr, win_w);
+        if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
+        if (!queue) break;
+        __syncthreads();
+    }
 }
 
 // Team variant for large members: workgroup 2t is the chase workgroup of member t, workgroup 2t + 1

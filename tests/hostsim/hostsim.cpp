@@ -173,8 +173,24 @@ int hs_eigvals_ms(const double* W_in, int n, int nsmax, int win_w, double* mu_ou
     MsStats st;
     memset(&st, 0, sizeof(st));
     hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st, win_w);
-    if (stats_out) { stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps; }
+    if (stats_out) { stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps;
+                     stats_out[4] = st.ab_calls; stats_out[5] = st.ab_fail; stats_out[6] = st.ab_iters; }
     return info;
+}
+
+// The Aberth / Hyman small eigenvalue solver on its own: T upper Hessenberg n x n (column-major), z out.
+// Returns the solver's verdict (1 = converged).
+int hs_aberth(const double* T_in, int n, double* z_out) {
+    std::vector<cd> T(n * n), U(n * n), D(n * n), zw(2 * n), z(n);
+    memcpy(T.data(), T_in, sizeof(cd) * n * n);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, 1024);
+    WaveCtx<HostCtx> wc{ctx, nullptr, 0};
+    std::vector<cd> zr(3 * n);
+    const bool ok = (n == 8) ? aberth_eigs_reg<8>(wc, T.data(), n, z.data(), zr.data(), 40, nullptr)
+                             : aberth_eigs(wc, n, T.data(), n, z.data(), U.data(), D.data(), zw.data(), 40);
+    memcpy(z_out, z.data(), sizeof(cd) * n);
+    return ok ? 1 : 0;
 }
 
 // Same, through the workgroup-TEAM code path: the helper workgroup's share of every record is run

@@ -68,6 +68,42 @@ def test_eig_random(hs):
         assert np.abs(mu[:, None] - ref[None, :]).min(axis=1).max() < 1e-11
 
 
+def test_aberth_shift_solver(hs):
+    """Ehrlich-Aberth on Hyman's recurrence (kb_hqr_ms.hpp::aberth_eigs): all eigenvalues of small unreduced
+    Hessenberg matrices to a few ulp - random ones and the nearly triangular trailing blocks of a QR iteration
+    in progress (tiny subdiagonals); and the multishift iteration that uses it hardly ever falls back."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(11)
+    for n in (3, 5, 8, 16, 24):
+        for trial in range(6):
+            A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+            T = sla.hessenberg(A)
+            if trial >= 3:      # graded subdiagonal, as in a converging trailing block
+                for k in range(1, n):
+                    T[k, k - 1] *= 10.0 ** (-2.0 * trial * k / n)
+            Tf = np.asfortranarray(T)
+            z = np.zeros(n, complex)
+            ok = hs.hs_aberth(Tf.ctypes.data_as(P), n, z.ctypes.data_as(P))
+            assert ok == 1, (n, trial)
+            ref = np.linalg.eigvals(T)
+            err = np.abs(z[:, None] - ref[None, :]).min(axis=1).max()
+            assert err < 1e-12 * np.abs(T).max(), (n, trial, err)
+            # every reference eigenvalue is found exactly once
+            assert len(set(np.abs(z[:, None] - ref[None, :]).argmin(axis=1))) == n
+    # exactly reducible matrix: the solver declines (caller falls back to the QR solver)
+    T = np.asfortranarray(np.triu(rng.standard_normal((6, 6)) + 0j))
+    z = np.zeros(6, complex)
+    assert hs.hs_aberth(T.ctypes.data_as(P), 6, z.ctypes.data_as(P)) == 0
+    # inside the multishift iteration
+    n = 150
+    W = np.asfortranarray(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    mu, st = np.zeros(n, complex), np.zeros(8, np.int64)
+    assert hs.hs_eigvals_ms(W.ctypes.data_as(P), n, 8, 56, mu.ctypes.data_as(P), st.ctypes.data_as(P)) == 0
+    ref = np.linalg.eigvals(W)
+    assert np.abs(mu[:, None] - ref[None, :]).min(axis=1).max() < 1e-11
+    assert st[4] > 10 and st[5] <= st[4] // 10, st
+
+
 def test_team_protocol_bookkeeping_matches_solo(hs):
     """The two-workgroup TEAM variant of the QR iteration (chase workgroup + helper workgroup,
     kb_hqr_ms.hpp) with the helper's share run inline: same tile partition, record ring and counters as
