@@ -97,7 +97,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, help="ensembles (steps) in flight at once")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="ensembles (steps) in flight at once (each has its own plan and streams; more than two "
+                         "would need more hardware queues than the runtime provides)")
     ap.add_argument("--workload", default="C2", choices=["C2", "C3small"])
     args = ap.parse_args()
 
@@ -237,7 +239,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/), if any
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_end_pmc_traffic.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_last_pmc_traffic.json")))["kernels"]
             # lane 0 runs the QR iteration as k_hqr_team; k_gen is templated on the register chunk count
             for key in (dom + "_team", dom, dom.split("(")[0], dom.split("(")[0] + "<8>"):
                 if key in pmc:

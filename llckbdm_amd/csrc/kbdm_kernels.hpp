@@ -127,17 +127,6 @@ __device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
     constexpr int NCH = 2 * KB_NB / KB_TU_KC;
-    // the C tile is fetched up front: its latency hides under the whole k loop
-    cd cv[2][2][4];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const cd* pc = Cptr(wr + rb * 16 + li, wc + cb * 16 + lk + 4 * g);
-                cv[cb][rb][g] = pc ? *pc : czero();
-            }
     cd ga[2], gb[2];
     ga[0] = Aop(srow, sk); ga[1] = Aop(srow, sk + 4);
     gb[0] = Bop(srow, sk); gb[1] = Bop(srow, sk + 4);
@@ -193,7 +182,7 @@ __device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
             for (int g = 0; g < 4; ++g) {
                 cd* pc = Cptr(wr + rb * 16 + li, wc + cb * 16 + lk + 4 * g);
                 if (pc) {
-                    cd v = cv[cb][rb][g];
+                    cd v = *pc;
                     v.x -= acc_re[cb][rb][g];
                     v.y -= acc_im[cb][rb][g];
                     *pc = v;

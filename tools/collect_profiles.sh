@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root:
 #   bash tools/collect_profiles.sh <tag>
-# Three separate rocprofv3 passes of the same bench command (kernel trace + stats; PMC FETCH_SIZE;
-# PMC WRITE_SIZE - counters are collected on their own, MI355X_MICROARCH.md), then the summaries are
-# written to gpurun_out/<tag>_* ; copy them into profiles/ afterwards.
+# Four separate rocprofv3 passes of the same bench command (kernel trace + stats; PMC FETCH_SIZE;
+# PMC WRITE_SIZE; PMC MFMA busy cycles - counters are collected on their own, MI355X_MICROARCH.md), then the
+# summaries are written to gpurun_out/<tag>_* ; copy them into profiles/ afterwards.
 set -e
 TAG=${1:-r1}
 ROOT=$(pwd)
@@ -11,9 +11,11 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $CMD > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.log
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- $CMD > /dev/null 2> $OUT/${TAG}_fetch.log
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- $CMD > /dev/null 2> $OUT/${TAG}_write.log
+timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_mfma -- $CMD > /dev/null 2> $OUT/${TAG}_mfma.log
 cd $ROOT
 python3 tools/summarise_profiles.py $TAG
+python3 tools/mfma_util.py $(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1) $(find $OUT/${TAG}_mfma -name "*counter_collection.csv" | head -1) > $OUT/${TAG}_north_star_kernels.json

@@ -1,68 +1,70 @@
-"""MFMA utilisation of the rank-64 trailing updates and HBM rate of the Hankel build from a rocprofv3 kernel trace
-of `bench.py` (C2).  usage: python tools/mfma_util.py <kernel_trace.csv> [lane0_members]"""
-import csv, json, sys
-import numpy as np
+"""The two figures BASELINE.json's north_star asks for besides the headline, from the rocprofv3 outputs of
+tools/collect_profiles.sh (workload C2):
+  * MFMA utilisation of the rank-64 trailing updates of the two blocked reductions (k_trail_update = the SVD panel
+    update, k_hess_update): (a) SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs) from the
+    PMC pass, where every kernel runs on its own; (b) algorithmic flops / summed launch durations from the kernel
+    trace of the normal (overlapped) run, against the 78.6 TFLOP/s FP64 matrix peak;
+  * HBM rate of the Hankel build k_hankel: algorithmic bytes (16 m^2 written + 32 m read per member: inside the
+    pipeline only U^{p-1} is materialised) / launch duration, against 8 TB/s.
+usage: python tools/mfma_util.py <kernel_trace.csv> [<counter_collection.csv>]"""
+import csv
+import json
+import sys
 
-PEAK = 78.6e12
-NB = 32
-ms_all = np.arange(100, 401, 2)[::-1]            # sorted by size, largest first (plan order)
-n0 = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-lanes = {32 if n0 == 32 else n0: ms_all[:n0], len(ms_all) - n0: ms_all[n0:]}
+PEAK_TFLOPS = 78.6
+NB, NX = 32, 64
+MS = list(range(100, 401, 2))
+
 
 def npanels(m):
-    return max(0, (m - 64) // NB) if m >= 2 * 64 else max(0, (m - 64) // NB)
+    return (m - NX) // NB if m >= NB + NX else 0
+
+
+def flops_svd(m):       # C[nn x nn] -= [V|X] [Y|U]^H, K = 64, per panel
+    return sum(8.0 * 2 * NB * (m - (p + 1) * NB) ** 2 for p in range(npanels(m)))
+
+
+def flops_hess(m):      # W[:, cbase:] -= [Y|V] [V|Z]^H, all n rows
+    return sum(8.0 * 2 * NB * m * (m - (p + 1) * NB) for p in range(npanels(m)))
+
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-out = {}
-for kname, kind in (("k_trail_update", "svd"), ("k_hess_update", "hess")):
+nsteps = len([r for r in rows if r["Kernel_Name"].startswith("k_hankel")]) / 2.0     # two lanes per step
+out = {"steps_in_trace": nsteps}
+for kname, fl in (("k_trail_update", sum(flops_svd(m) for m in MS)), ("k_hess_update", sum(flops_hess(m) for m in MS))):
     sel = [r for r in rows if r["Kernel_Name"].startswith(kname)]
-    # the panel index of a launch: launches of one lane come in panel order; identify the lane by Grid_Size_Z
-    per = {}
-    tot_f = tot_t = 0.0
-    seen = {}
-    for r in sel:
-        z = int(r["Grid_Size_Z"])
-        members = lanes.get(z)
-        if members is None:
-            continue
-        gx = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
-        gy = int(r["Grid_Size_Y"])
-        # panel from the grid: trailing size of the largest member
-        mmax = int(members[0])
-        if kind == "svd":
-            # grid = ceil((mmax - p0 - NB) / 64)
-            cands = [p for p in range(0, 40) if (mmax - p * NB - NB + 63) // 64 == gx and mmax - p * NB - NB > 0]
-        else:
-            cands = [p for p in range(0, 40) if (mmax - (p + 1) * NB + 63) // 64 == gy and mmax - (p + 1) * NB > 0]
-        key = (z, gx, gy)
-        idx = seen.get(key, 0)
-        seen[key] = idx + 1
-        nsteps = len([1 for r2 in sel if int(r2["Grid_Size_Z"]) == z and int(r2["Grid_Size_X"]) // int(r2["Workgroup_Size_X"]) == gx and int(r2["Grid_Size_Y"]) == gy])
-        per_step = max(1, len(cands))
-        p = cands[(idx % per_step)] if cands else 0
-        fl = 0.0
-        for m in members:
-            m = int(m)
-            if kind == "svd":
-                nn = m - p * NB - NB
-                if nn > 0 and p < (m - 64) // NB + (1 if (m - 64) % NB == 0 and False else 0) + 1:
-                    fl += 8.0 * 2 * NB * nn * nn
-            else:
-                nc = m - (p + 1) * NB
-                if nc > 0:
-                    fl += 8.0 * 2 * NB * m * nc
-        dt = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-        tot_f += fl
-        tot_t += dt
-    out[kname] = {"launches": len(sel), "tflops": tot_f / tot_t / 1e12 if tot_t else None,
-                  "frac_of_fp64_mfma_peak": tot_f / tot_t / PEAK if tot_t else None, "total_ms": 1e3 * tot_t}
+    t = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel) * 1e-9
+    out[kname] = {"launches": len(sel), "algorithmic_gflop_per_step": fl / 1e9, "summed_ms_per_step": 1e3 * t / nsteps,
+                  "tflops_over_launch_time": fl * nsteps / t / 1e12, "frac_of_fp64_matrix_peak": fl * nsteps / t / 1e12 / PEAK_TFLOPS}
 hk = [r for r in rows if r["Kernel_Name"].startswith("k_hankel")]
-b = t = 0.0
-for r in hk:
-    members = lanes.get(int(r["Grid_Size_Z"]))
-    if members is None:
-        continue
-    b += sum(16.0 * int(m) * int(m) + 16.0 * (2 * int(m)) for m in members)
-    t += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-out["k_hankel"] = {"launches": len(hk), "GBps": b / t / 1e9 if t else None, "frac_of_hbm_peak": b / t / 8e12 if t else None}
+t = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in hk) * 1e-9
+b = sum(16.0 * m * m + 32.0 * m for m in MS)
+out["k_hankel"] = {"launches": len(hk), "algorithmic_MB_per_step": b / 1e6, "GBps": b * nsteps / t / 1e9,
+                   "frac_of_hbm_peak": b * nsteps / t / 8e12}
+if len(sys.argv) > 2:
+    acc = {}
+    for r in csv.DictReader(open(sys.argv[2])):
+        k = r["Kernel_Name"].split("(")[0]
+        acc.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    # per launch (the PMC pass runs every kernel on its own): the big first-panel launches against the small last ones
+    per = {}
+    for r in csv.DictReader(open(sys.argv[2])):
+        k = r["Kernel_Name"].split("(")[0]
+        if k in ("k_trail_update", "k_hess_update"):
+            d = per.setdefault((k, r["Dispatch_Id"]), {"wgs": int(r["Grid_Size"]) // 256})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    for k in ("k_trail_update", "k_hess_update"):
+        ls = sorted((d for (kk, _), d in per.items() if kk == k and d.get("GRBM_GUI_ACTIVE")), key=lambda d: -d["wgs"])
+        if ls:
+            util = [d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4) for d in ls]
+            big = [u for d, u in zip(ls, util) if d["wgs"] == ls[0]["wgs"]]
+            small = [u for d, u in zip(ls, util) if d["wgs"] == ls[-1]["wgs"]]
+            out[k]["pmc_mfma_utilisation_largest_launches"] = {"workgroups": ls[0]["wgs"], "mean": sum(big) / len(big), "max": max(big)}
+            out[k]["pmc_mfma_utilisation_smallest_launches"] = {"workgroups": ls[-1]["wgs"], "mean": sum(small) / len(small)}
+    for k in ("k_trail_update", "k_hess_update"):
+        v = acc.get(k)
+        if v and v.get("GRBM_GUI_ACTIVE"):
+            out[k]["pmc_mfma_busy_cycles"] = v["SQ_VALU_MFMA_BUSY_CYCLES"]
+            out[k]["pmc_mfma_utilisation"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
 print(json.dumps(out, indent=1))
