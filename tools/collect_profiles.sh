@@ -15,7 +15,8 @@ rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $CMD > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.log
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- $CMD > /dev/null 2> $OUT/${TAG}_fetch.log
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- $CMD > /dev/null 2> $OUT/${TAG}_write.log
-timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_mfma -- $CMD > /dev/null 2> $OUT/${TAG}_mfma.log
+timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_mfma -- $CMD --in-flight 1 > /dev/null 2> $OUT/${TAG}_mfma.log
 cd $ROOT
 python3 tools/summarise_profiles.py $TAG
-python3 tools/mfma_util.py $(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1) $(find $OUT/${TAG}_mfma -name "*counter_collection.csv" | head -1) > $OUT/${TAG}_north_star_kernels.json
+# (the MFMA pass runs one ensemble at a time so that a launch's busy cycles are not diluted by the other ensemble)
+python3 tools/mfma_util.py $(find $OUT/${TAG}_mfma -name "*kernel_trace.csv" | head -1) $(find $OUT/${TAG}_mfma -name "*counter_collection.csv" | head -1) > $OUT/${TAG}_north_star_kernels.json
