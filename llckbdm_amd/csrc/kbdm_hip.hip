@@ -80,7 +80,9 @@ struct kbdm_ctx {
     int invit_reg = 1;    // inverse iteration with register-resident vectors for l <= 512 (0: the LDS form)
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
-    int hqr_wgs = 64;     // workgroups of the solo k_hqr launch: members are taken from a queue, largest first
+    int hqr_wgs = -1;     // workgroups of the solo k_hqr launch (members are taken from a queue, largest first):
+                          // -1 = as many as the launch's work needs to last no longer than its largest member,
+                          // 0 = one workgroup per member, N = fixed
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
 };
@@ -260,6 +262,7 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_keep, std::max<int64_t>(pl->total_lines, 1)));
     HIPCHK(hipMalloc(&pl->d_status, sizeof(int) * B));
     HIPCHK(hipMalloc(&pl->d_iwork, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
+    HIPCHK(hipMemset(pl->d_iwork, 0, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
     HIPCHK(hipMalloc(&pl->d_team, sizeof(TeamCtl) * std::max(B, 1)));
     HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS * team_rec_bytes(pl->ctx->ns_hqr, std::max(pl->ctx->win_hqr, 8))));
     HIPCHK(hipMalloc(&pl->d_rot, sizeof(Rot) * std::max<size_t>(pl->rot_elems, 1)));
@@ -439,8 +442,21 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             // does not occupy go to the other lane's / the next ensemble's throughput-bound stages
             const int nsolo = ch.count - nteam;
             const int cidx = (int)(&ch - pl->chunks.data());
-            int* queue = (ctx->hqr_wgs > 0 && nsolo > ctx->hqr_wgs && cidx < KB_QUEUE_WORDS) ? pl->d_iwork + 4 * pl->B + cidx : nullptr;
-            hipLaunchKernelGGL(k_hqr, dim3(queue ? ctx->hqr_wgs : nsolo), dim3(ctx->nt_hqr), sm, ss, pl->d_items, perm + nteam,
+            int nwg = ctx->hqr_wgs;
+            if (nwg < 0) {
+                // the iteration costs ~l^2 per member: sum l^2 / lmax^2 workgroups keep pace with the largest
+                // member (15 % slack for the greedy packing); a large batch gets one workgroup per member
+                double work = 0.0, lmax = 1.0;
+                for (int i = nteam; i < ch.count; ++i) {
+                    const double l = pl->items[pl->perm[ch.first + i]].l;
+                    work += l * l;
+                    lmax = std::max(lmax, l);
+                }
+                nwg = (int)std::ceil(1.15 * work / (lmax * lmax));
+                if (nwg > 192) nwg = 0;
+            }
+            int* queue = (nwg > 0 && nsolo > nwg && cidx < KB_QUEUE_WORDS) ? pl->d_iwork + 4 * pl->B + cidx : nullptr;
+            hipLaunchKernelGGL(k_hqr, dim3(queue ? nwg : nsolo), dim3(ctx->nt_hqr), sm, ss, pl->d_items, perm + nteam,
                                pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof, nsolo, queue);
             if (nteam > 0) HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));   // the join now covers Qh and the solo members
         }
@@ -589,7 +605,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
     c->invit_reg = env_int("KBDM_INVIT_REG", c->invit_reg);
     c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
-    c->hqr_wgs = std::max(0, env_int("KBDM_HQR_WGS", c->hqr_wgs));
+    c->hqr_wgs = std::max(-1, env_int("KBDM_HQR_WGS", c->hqr_wgs));
     c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
     if (c->nt_hqr > 512) c->nt_hqr = 512;
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
@@ -880,6 +896,7 @@ int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, doub
         if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
         hipMemcpy(d_dense, W, sizeof(cd) * tot, hipMemcpyHostToDevice);
         hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
+        hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * B + KB_QUEUE_WORDS), st);     // member-queue counters
         hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * B, st);
         Chunk& ch = pl->chunks[0];
         hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_P, 1);

@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(512) k_hqr(const KbItem* __restrict__ items, c
             idx = next;
             __syncthreads();
         }
-        if (idx >= count) break;
+        if ((unsigned)idx >= (unsigned)count) break;
         const int item = perm[idx];
         const KbItem it = items[item];
         cd* Hc = arena + it.off[KB_BUF_H];

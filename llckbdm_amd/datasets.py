@@ -52,3 +52,29 @@ def config3(count=1024, m=512, seed0=0):
     base = brain_sim_signal(2048)
     sigs = np.stack([add_noise(base, 1e-6, seed0 + k) for k in range(count)])
     return sigs, np.arange(count, dtype=np.int32), np.full(count, m, dtype=np.int32)
+
+
+def config4(mmin=200, mmax=1200, step=1):
+    """C4: N=4096, the 16 table peaks + 16 seeded extra peaks, sigma=1e-3, m = 200..1200 (1001 members)."""
+    rng = np.random.default_rng(1)
+    extra = np.column_stack([rng.uniform(0.01, 1, 16), rng.uniform(0.005, 0.2, 16), rng.uniform(50, 950, 16),
+                             np.zeros(16)])
+    params = np.vstack([BRAIN_SIM_PARAMS, extra])
+    t = np.arange(4096) * DWELL
+    sig = add_noise(sig_gen.multi_fid(t, params), 1e-3, 4)
+    m = np.arange(mmin, mmax + 1, step, dtype=np.int32)
+    return sig.reshape(1, -1), np.zeros(len(m), dtype=np.int32), m
+
+
+def config5(voxels=64, mmin=128, mmax=383):
+    """C5: multi-voxel grid, `voxels` signals (table peaks with amplitudes scaled by U(0.5, 1.5), sigma=1e-3,
+    N=2048) x an m-ensemble m = 128..383 each (64 x 256 = 16384 members)."""
+    t = np.linspace(0, DWELL * 2048, 2048, endpoint=False)
+    sigs = []
+    for v in range(voxels):
+        p = BRAIN_SIM_PARAMS.copy()
+        p[:, 0] *= np.random.default_rng(100 + v).uniform(0.5, 1.5, len(p))
+        sigs.append(add_noise(sig_gen.multi_fid(t, p), 1e-3, 50 + v))
+    ms = np.arange(mmin, mmax + 1, dtype=np.int32)
+    sig_idx = np.repeat(np.arange(voxels, dtype=np.int32), len(ms))
+    return np.stack(sigs), sig_idx, np.tile(ms, voxels)

@@ -1,0 +1,64 @@
+"""BASELINE.json configs 3-5 at their FULL sizes (1024 x m=512; m = 200..1200 at N=4096; 64 voxels x 256 members)
+through the C ABI, checked by size-independent properties (the oracle would need minutes to hours here):
+status words, Frobenius identity sum s_i^2 = ||U^0||_F^2 of the singular values, their ordering, finite kept
+lines, and bit-identical results for a member solved on its own (chunking, lanes, team / solo / queued kernels and
+replay grouping must not change a single bit).  Reduced-size versions of the same shapes are compared with the
+oracle line by line in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from llckbdm_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _check(eng, sigs, sig_idx, ms, nsample=24):
+    from llckbdm_amd import datasets
+    res = eng.solve(sigs, sig_idx, ms, None, p=1, q=0.0, dwell=datasets.DWELL)
+    assert not (res.status & 3).any()                 # SVD / eigenvalue iteration converged everywhere
+    B = len(ms)
+    rng = np.random.default_rng(0)
+    pick = sorted(set([0, B - 1] + [int(x) for x in rng.integers(0, B, nsample)]))
+    for i in pick:
+        m = int(ms[i])
+        sig = sigs[sig_idx[i]]
+        sv = res.singular_values(i)
+        assert np.all(np.diff(sv) <= 0) and sv[-1] >= 0
+        cnt = np.minimum(np.arange(2 * m - 1) + 1, 2 * m - 1 - np.arange(2 * m - 1))
+        fro2 = float(np.sum(cnt * np.abs(sig[:2 * m - 1]) ** 2))
+        assert abs(np.sum(sv ** 2) - fro2) < 1e-12 * fro2
+        ll = res.line_list(i)
+        assert ll.shape == (m, 4) and np.isfinite(ll[res.keep_mask(i)]).all()
+        assert res.keep_mask(i).sum() >= 16           # at least the true peaks survive the filter
+    for i in (pick[0], pick[len(pick) // 2], pick[-1]):
+        solo = eng.solve(sigs[sig_idx[i]].reshape(1, -1), [0], [int(ms[i])], None, p=1, q=0.0, dwell=datasets.DWELL)
+        assert np.array_equal(solo.line_list(0), res.line_list(i))
+        assert np.array_equal(solo.singular_values(0), res.singular_values(i))
+    return res
+
+
+def test_config3_full_1024_draws_m512(eng):
+    from llckbdm_amd import datasets
+    sigs, sig_idx, ms = datasets.config3()
+    assert len(ms) == 1024 and set(ms) == {512}
+    _check(eng, sigs, sig_idx, ms)
+
+
+def test_config5_full_64_voxels_x_256_members(eng):
+    from llckbdm_amd import datasets
+    sigs, sig_idx, ms = datasets.config5()
+    assert len(ms) == 16384 and sigs.shape == (64, 2048)
+    _check(eng, sigs, sig_idx, ms)
+
+
+def test_config4_full_m200_to_1200_N4096(eng):
+    from llckbdm_amd import datasets
+    sigs, sig_idx, ms = datasets.config4()
+    assert len(ms) == 1001 and sigs.shape == (1, 4096) and ms[-1] == 1200
+    _check(eng, sigs, sig_idx, ms, nsample=12)
