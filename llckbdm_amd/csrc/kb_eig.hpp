@@ -52,12 +52,16 @@ KB_HD void gehd2(const C& ctx, int n, cd* W, int ld, cd* tauh, int k0 = 0) {
 }
 
 // ---------------------------------------------------------------------------------
-// Blocked Hessenberg reduction.  With  A H_j = A - y_j v_j^H  and  H_j^H (.) = (.) - v_j z_j^H  the
-// matrix after j reflectors of a panel is  A^(j) = A0 - Y_j V_j^H - V_j Z_j^H ,
-//   y_j = tau_j A^(j) v_j ,   z_j = tau_j ((A^(j))^H v_j - v_j (y_j^H v_j)) ,
-// so only the current column is formed explicitly inside a panel of KB_NB columns (two
-// matrix-vector products with the untouched A0 per column), and all columns to the right of the
-// panel receive ONE rank-2NB update afterwards (k_hess_update, FP64 MFMA, all CUs).
+// Blocked Hessenberg reduction (zgehrd / zlahr2 organisation).  With Q = H_0 ... H_{j-1} = I - V T V^H the matrix
+// after j reflectors of a panel is  A^(j) = Q^H A0 Q,  A0 Q = A0 - Y V^H  with  Y = A0 V T:
+//   y_j = tau_j (A0 v_j - Y_j (V_j^H v_j)) ,   T(0:j, j) = -tau_j T_j (V_j^H v_j) ,  T(j, j) = tau_j ,
+// so inside a panel of KB_NB columns only the current column is formed explicitly,
+//   x = A0(:, k) - Y_j V_j(k, :)^H ,   column k of A^(j) = x - V_j T_j^H (V_j^H x) ,
+// and the untouched A0 is streamed ONCE per column (the product A0 v_j; the left factors never need a pass of
+// their own inside the panel).  All columns to the right of the panel then receive ONE rank-2NB update
+//   A <- A0 - Y V^H - V Z^H ,   Z = (A0^H V - V (Y^H V)) T = A0^H (V T) - V (Y^H V T)
+// (k_hess_z: one more pass over the trailing columns for all NB vectors at once, then k_hess_update on FP64
+// MFMA).  The panel leaves VT = V T (N x NB) and MT = (Y^H V) T (NB x NB) for k_hess_z.
 // v_t (panel column t, global column kt = p0 + t): rows > kt+1 stored in W[.., kt], implicit 1 at
 // row kt+1, zero above.
 KB_HD cd hess_vt(const cd* W, int ld, int p0, int r, int t) {
@@ -66,31 +70,55 @@ KB_HD cd hess_vt(const cd* W, int ld, int p0, int r, int t) {
 }
 KB_HD int hess_panel_scratch_bytes(int n, int nwaves, int ws) {
     int z = n > nwaves * ws ? n : nwaves * ws;
-    return (n + z + 3 * KB_NB + 8) * (int)sizeof(cd);
+    return (n + z + 2 * KB_NB + KB_NB * KB_NB + 8) * (int)sizeof(cd);
 }
 
 template <class C>
-KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* Y, cd* Z, int ldyz) {
+KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* Y, int ldy, cd* VT, int ldvt,
+                      cd* MT) {
 #define W_(r_, c_) W[(r_) + (size_t)(c_) * ld]
-#define Y_(r_, c_) Y[(r_) + (size_t)(c_) * ldyz]
-#define Z_(r_, c_) Z[(r_) + (size_t)(c_) * ldyz]
+#define Y_(r_, c_) Y[(r_) + (size_t)(c_) * ldy]
+#define T_(r_, c_) Tm[(r_) + (c_) * KB_NB]
     const int tid = ctx.tid(), nt = ctx.nthreads(), lane = ctx.lane();
     cd* ub = reinterpret_cast<cd*>(ctx.scratch());           // v (indexed by global row)
     cd* zp = ub + N;
     const int zcap = N > ctx.nwaves() * C::WS ? N : ctx.nwaves() * C::WS;
-    cd* w1 = zp + zcap;
-    cd* w2 = w1 + KB_NB;
-    cd* w3 = w2 + KB_NB;
+    cd* w1 = zp + zcap;                                      // V^H v  /  V^H x
+    cd* w2 = w1 + KB_NB;                                     // T^H (V^H x)
+    cd* Tm = w2 + KB_NB;                                     // T, NB x NB upper triangular
+    for (int idx = tid; idx < KB_NB * KB_NB; idx += nt) Tm[idx] = czero();
+    ctx.sync();
     for (int j = 0; j < KB_NB; ++j) {
         const int k = p0 + j;
-        // ---- 1. column k of A^(j), all rows
+        // ---- 1a. x = A0(:, k) - Y_j V_j(k, :)^H, all rows
         for (int r = tid; r < N; r += nt) {
             cd acc = W_(r, k);
-            for (int t = 0; t < j; ++t)
-                acc = acc - Y_(r, t) * conj(hess_vt(W, ld, p0, k, t)) - hess_vt(W, ld, p0, r, t) * conj(Z_(k, t));
+            for (int t = 0; t < j; ++t) acc = acc - Y_(r, t) * conj(hess_vt(W, ld, p0, k, t));
             W_(r, k) = acc;
         }
         ctx.sync();
+        if (j > 0) {
+            // ---- 1b. w1 = V_j^H x (one wavefront per dot product), w2 = T_j^H w1, x -= V_j w2
+            for (int t = ctx.wave(); t < j; t += ctx.nwaves()) {
+                cd acc = czero();
+                for (int r = p0 + t + 1 + lane; r < N; r += C::WS) cfmac(acc, hess_vt(W, ld, p0, r, t), W_(r, k));
+                acc = ctx.wave_sum(acc);
+                if (lane == 0) w1[t] = acc;
+            }
+            ctx.sync();
+            for (int t = tid; t < j; t += nt) {
+                cd acc = czero();
+                for (int s2 = 0; s2 <= t; ++s2) cfmac(acc, T_(s2, t), w1[s2]);    // (T^H w1)_t = sum_s conj(T(s,t)) w1_s
+                w2[t] = acc;
+            }
+            ctx.sync();
+            for (int r = p0 + 1 + tid; r < N; r += nt) {
+                cd acc = W_(r, k);
+                for (int t = 0; t < j; ++t) acc = acc - hess_vt(W, ld, p0, r, t) * w2[t];
+                W_(r, k) = acc;
+            }
+            ctx.sync();
+        }
         // ---- 2. reflector from rows k+1..N-1
         double beta;
         cd tau;
@@ -99,20 +127,15 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
         for (int r = k + 1 + tid; r < N; r += nt) ub[r] = (r == k + 1) ? mk(1.0, 0.0) : W_(r, k);
         ctx.sync();
         if (tid == 0) { tauh[j] = tau; W_(k + 1, k) = mk(beta, 0.0); }
-        // ---- 3. w1 = V^H v, w2 = Z^H v, w3 = Y^H v  (one wavefront per dot product)
-        for (int q = ctx.wave(); q < 3 * j; q += ctx.nwaves()) {
-            const int which = q / j, t = q % j;
+        // ---- 3. w1 = V_j^H v
+        for (int t = ctx.wave(); t < j; t += ctx.nwaves()) {
             cd acc = czero();
-            for (int r = k + 1 + lane; r < N; r += C::WS) {
-                const cd a = (which == 0) ? hess_vt(W, ld, p0, r, t) : ((which == 1) ? Z_(r, t) : Y_(r, t));
-                cfmac(acc, a, ub[r]);
-            }
+            for (int r = k + 1 + lane; r < N; r += C::WS) cfmac(acc, hess_vt(W, ld, p0, r, t), ub[r]);
             acc = ctx.wave_sum(acc);
-            if (lane == 0) { if (which == 0) w1[t] = acc; else if (which == 1) w2[t] = acc; else w3[t] = acc; }
+            if (lane == 0) w1[t] = acc;
         }
         ctx.sync();
-        // ---- 4. y = tau (A0[:, k+1:] v - Y w1 - V w2), all rows; yv = y^H v
-        cd yv;
+        // ---- 4. y = tau (A0[:, k+1:] v - Y_j w1), all rows: the one pass over A0 of this column
         {
             const int ncols = N - k - 1;
             const int nw = ctx.nwaves();
@@ -137,51 +160,60 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
                 }
             }
             ctx.sync();
-            cd part = czero();
             for (int r = tid; r < N; r += nt) {
                 cd h = czero();
                 for (int g = 0; g < ncg; ++g) h += zp[g * N + r];
-                for (int t = 0; t < j; ++t) h = h - Y_(r, t) * w1[t] - hess_vt(W, ld, p0, r, t) * w2[t];
-                const cd y = tau * h;
-                Y_(r, j) = y;
-                if (r >= k + 1) cfmac(part, y, ub[r]);
-            }
-            yv = ctx.block_sum(part);
-        }
-        // ---- 5. z = tau (A0[k+1:, k+1:]^H v - V w3 - Z w1 - v yv), columns k+1..N-1
-        // two columns per wavefront at a time, two row chunks each: four loads in flight per lane
-        for (int c0 = k + 1 + 2 * ctx.wave(); c0 < N; c0 += 2 * ctx.nwaves()) {
-            const int c1 = (c0 + 1 < N) ? c0 + 1 : c0;
-            cd g0 = czero(), g1 = czero(), h0 = czero(), h1 = czero();
-            int r = k + 1 + lane;
-            for (; r + C::WS < N; r += 2 * C::WS) {
-                const cd a00 = W_(r, c0), a01 = W_(r, c1), a10 = W_(r + C::WS, c0), a11 = W_(r + C::WS, c1);
-                const cd v0 = ub[r], v1 = ub[r + C::WS];
-                cfmac(g0, a00, v0); cfmac(g1, a01, v0); cfmac(h0, a10, v1); cfmac(h1, a11, v1);
-            }
-            for (; r < N; r += C::WS) {
-                const cd a00 = W_(r, c0), a01 = W_(r, c1);
-                const cd v0 = ub[r];
-                cfmac(g0, a00, v0); cfmac(g1, a01, v0);
-            }
-            cd corr0 = czero(), corr1 = czero();
-            for (int t = lane; t < j; t += C::WS) {
-                corr0 = corr0 + hess_vt(W, ld, p0, c0, t) * w3[t] + Z_(c0, t) * w1[t];
-                corr1 = corr1 + hess_vt(W, ld, p0, c1, t) * w3[t] + Z_(c1, t) * w1[t];
-            }
-            const cd s0 = ctx.wave_sum((g0 + h0) - corr0);
-            const cd s1 = ctx.wave_sum((g1 + h1) - corr1);
-            if (lane == 0) {
-                Z_(c0, j) = tau * (s0 - ub[c0] * yv);
-                if (c0 + 1 < N) Z_(c0 + 1, j) = tau * (s1 - ub[c0 + 1] * yv);
+                for (int t = 0; t < j; ++t) h = h - Y_(r, t) * w1[t];
+                Y_(r, j) = tau * h;
             }
         }
-        for (int c = tid; c <= k; c += nt) Z_(c, j) = czero();
+        // ---- 5. T(0:j, j) = -tau T_j w1, T(j, j) = tau
+        for (int t = tid; t <= j; t += nt) {
+            if (t == j) T_(j, j) = tau;
+            else {
+                cd acc = czero();
+                for (int s2 = t; s2 < j; ++s2) cfma(acc, T_(t, s2), w1[s2]);
+                T_(t, j) = -(tau * acc);
+            }
+        }
         ctx.sync();
     }
+    // ---- VT = V T (all rows; rows <= p0 are zero) and MT = (Y^H V) T for the deferred left factor
+    for (int r = tid; r < N; r += nt)
+        for (int t = 0; t < KB_NB; ++t) {
+            cd acc = czero();
+            for (int s2 = 0; s2 <= t; ++s2) cfma(acc, hess_vt(W, ld, p0, r, s2), T_(s2, t));
+            VT[r + (size_t)t * ldvt] = acc;
+        }
+    ctx.sync();
+    // (Y^H V T)(u, t) = sum_r conj(Y(r,u)) VT(r,t): one wavefront per entry
+    for (int e = ctx.wave(); e < KB_NB * KB_NB; e += ctx.nwaves()) {
+        const int u = e % KB_NB, t = e / KB_NB;
+        cd acc = czero();
+        for (int r = p0 + 1 + lane; r < N; r += C::WS) cfmac(acc, Y_(r, u), VT[r + (size_t)t * ldvt]);
+        acc = ctx.wave_sum(acc);
+        if (lane == 0) MT[u + t * KB_NB] = acc;
+    }
+    ctx.sync();
 #undef W_
 #undef Y_
-#undef Z_
+#undef T_
+}
+
+// Deferred left factor of one panel for the trailing columns c in [c_begin, c_end):
+//   Z(c, t) = sum_r conj(A0(r, c)) VT(r, t) - sum_u V(c, u) MT(u, t)          (reference form; the device kernel
+// k_hess_z computes the same sums tiled through LDS).
+template <class C>
+KB_HD void hess_z_block(const C& ctx, int N, const cd* W, int ld, int p0, const cd* VT, int ldvt, const cd* MT,
+                        cd* Z, int ldz, int c_begin, int c_end) {
+    for (int idx = ctx.tid(); idx < (c_end - c_begin) * KB_NB; idx += ctx.nthreads()) {
+        const int c = c_begin + idx % (c_end - c_begin), t = idx / (c_end - c_begin);
+        cd acc = czero();
+        for (int r = p0 + 1; r < N; ++r) cfmac(acc, W[r + (size_t)c * ld], VT[r + (size_t)t * ldvt]);
+        for (int u = 0; u < KB_NB; ++u) acc = acc - hess_vt(W, ld, p0, c, u) * MT[u + t * KB_NB];
+        Z[c + (size_t)t * ldz] = acc;
+    }
+    ctx.sync();
 }
 
 // Extract the upper Hessenberg part of W into the work copy Hc that the QR iteration destroys

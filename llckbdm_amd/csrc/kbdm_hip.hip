@@ -387,6 +387,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             hipLaunchKernelGGL(k_hess_panel, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
                                pl->d_arena, pl->d_varena, pnl, smp);
             const int ncol = ch.lmax - (pnl + 1) * KB_NB;
+            hipLaunchKernelGGL(k_hess_z, dim3((ncol + 63) / 64, ch.count), dim3(256), 0, st, pl->d_items, perm, pl->d_arena, pnl);
             hipLaunchKernelGGL(k_hess_update, dim3((ch.lmax + 63) / 64, (ncol + 63) / 64, ch.count), dim3(256), 0, st,
                                pl->d_items, perm, pl->d_arena, pnl);
         }

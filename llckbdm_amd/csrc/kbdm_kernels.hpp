@@ -478,7 +478,8 @@ __global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, 
 
 // ------------------------------------------------------------------------------------
 // Blocked Hessenberg reduction of W (KB_BUF_P): for panel p = 0, 1, ... (host loop)
-//   k_hess_panel   one workgroup per item: NB reflectors, Y -> KB_BUF_Q, Z -> KB_BUF_H
+//   k_hess_panel   one workgroup per item: NB reflectors, Y -> KB_BUF_Q; VT, MT -> KB_BUF_H (one pass over A0 per column)
+//   k_hess_z       all CUs: Z = A0^H VT - V MT for the columns right of the panel -> KB_BUF_H
 //   k_hess_update  all CUs: W[:, p0+NB:] -= [Y | V] [V | Z]^H  (FP64 MFMA tiles)
 // then k_hess finishes unblocked, extracts the work copy (KB_BUF_H) and ||H||_inf.
 __global__ void __launch_bounds__(1024) k_hess_panel(const KbItem* __restrict__ items, const int* __restrict__ perm,
@@ -490,9 +491,69 @@ __global__ void __launch_bounds__(1024) k_hess_panel(const KbItem* __restrict__ 
     const int p0 = panel * KB_NB;
     cd* W = arena + it.off[KB_BUF_P];
     cd* Y = arena + it.off[KB_BUF_Q];
-    cd* Z = arena + it.off[KB_BUF_H];
+    cd* Z = arena + it.off[KB_BUF_H];          // Z (n x NB), then MT (NB x NB), then VT (n x NB): n >= NB + NX
     cd* tauh = reinterpret_cast<cd*>(varena + it.voff + KB_V_TAUQ * it.vstride) + p0;
-    hess_panel(ctx, n, W, n, p0, tauh, Y, Z, n);
+    hess_panel(ctx, n, W, n, p0, tauh, Y, n, Z + (size_t)n * KB_NB + KB_NB * KB_NB, n, Z + (size_t)n * KB_NB);
+}
+
+// Deferred left factor of a panel, all CUs:  Z(c, :) = A0(:, c)^H VT - V(c, :) MT  for the columns right of the
+// panel (kb_eig.hpp, hess_z_block).  One workgroup = 64 columns x NB outputs; A0 and VT go through LDS in chunks
+// of 16 rows (A0 is read once per panel here instead of once per column inside the panel).
+__global__ void __launch_bounds__(256) k_hess_z(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                 cd* arena, int panel) {
+    const KbItem it = items[perm[blockIdx.y]];
+    const int n = it.l;
+    if (panel >= bidiag_num_panels(n)) return;
+    const int p0 = panel * KB_NB;
+    const int cbase = p0 + KB_NB;
+    const int c0 = cbase + blockIdx.x * 64;
+    if (c0 >= n) return;
+    const cd* W = arena + it.off[KB_BUF_P];
+    cd* Z = arena + it.off[KB_BUF_H];
+    const cd* MT = Z + (size_t)n * KB_NB;
+    const cd* VT = MT + KB_NB * KB_NB;
+    constexpr int RC = 16;
+    __shared__ cd sA[RC][64 + 1];
+    __shared__ cd sV[RC][KB_NB];
+    const int t = threadIdx.x;
+    const int cl = t & 63, tg = t >> 6;               // column of this thread, group of 8 outputs (uniform per wavefront)
+    cd acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = czero();
+    for (int r0 = p0 + 1; r0 < n; r0 += RC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = t + 256 * i;
+            const int rr = e & (RC - 1), cc = e >> 4;
+            const int r = r0 + rr, c = c0 + cc;
+            sA[rr][cc] = (r < n && c < n) ? W[r + (size_t)c * n] : czero();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = t + 256 * i;
+            const int rr = e & (RC - 1), tt = e >> 4;
+            const int r = r0 + rr;
+            sV[rr][tt] = (r < n) ? VT[r + (size_t)tt * n] : czero();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RC; ++rr) {
+            const cd a = sA[rr][cl];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) cfmac(acc[o], a, sV[rr][tg * 8 + o]);
+        }
+        __syncthreads();
+    }
+    const int c = c0 + cl;
+    if (c < n) {
+        for (int u = 0; u < KB_NB; ++u) {
+            const cd v = hess_vt(W, n, p0, c, u);           // V(c, u) (the head of the last reflector sits at c = cbase)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[o] = acc[o] - v * MT[u + (tg * 8 + o) * KB_NB];
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) Z[c + (size_t)(tg * 8 + o) * n] = acc[o];
+    }
 }
 
 __global__ void __launch_bounds__(256) k_hess_update(const KbItem* __restrict__ items, const int* __restrict__ perm,

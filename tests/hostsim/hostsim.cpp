@@ -121,10 +121,11 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
                                       hqr_win_scratch_bytes(8, 60, 1));
     {   // blocked Hessenberg reduction as the kernels sequence it: panels + updates + tail
         const int npan = bidiag_num_panels(n);
-        std::vector<cd> Yp((size_t)n * KB_NB), Zp((size_t)n * KB_NB);
+        std::vector<cd> Yp((size_t)n * KB_NB), Zp((size_t)n * KB_NB), VTp((size_t)n * KB_NB), MTp(KB_NB * KB_NB);
         for (int pnl = 0; pnl < npan; ++pnl) {
             const int p0 = pnl * KB_NB;
-            hess_panel(ctx, n, W.data(), n, p0, th.data() + p0, Yp.data(), Zp.data(), n);
+            hess_panel(ctx, n, W.data(), n, p0, th.data() + p0, Yp.data(), n, VTp.data(), n, MTp.data());
+            hess_z_block(ctx, n, W.data(), n, p0, VTp.data(), n, MTp.data(), Zp.data(), n, p0 + KB_NB, n);
             for (int c = p0 + KB_NB; c < n; ++c)
                 for (int r = 0; r < n; ++r) {
                     cd acc = W[r + (size_t)c * n];
