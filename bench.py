@@ -94,13 +94,15 @@ def cpu_baseline(sig, ms, dwell, min_seconds=12.0, max_passes=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
                     help="ensembles (steps) in flight at once (each has its own plan and streams; more than two "
                          "would need more hardware queues than the runtime provides)")
     ap.add_argument("--workload", default="C2", choices=["C2", "C3small"])
+    ap.add_argument("--no-stagger", dest="stagger", action="store_false",
+                    help="submit the second ensemble at once instead of when the first reaches its QR iteration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +182,10 @@ def main():
     def step(s):
         k = s % nfl
         finish(k)
+        if timed[0] and s == 1 and nfl == 2 and args.stagger:
+            # the two pipelines have the same cycle: started together they stay in phase (panels against panels,
+            # QR iteration against QR iteration); start the second one when the first reaches its QR iteration
+            plans[0].wait_stage("k_hess")
         plans[k].execute(sync=False)
         busy[k] = True
 

@@ -84,6 +84,11 @@ void* kbdm_plan_sv_device(kbdm_plan* plan);
 int kbdm_plan_copy_lines_device(kbdm_plan* plan, void* dst_device, int64_t dst_bytes);
 /* elapsed ms of each pipeline stage in the last execute (HIP events on the plan's stream);
  * also returns the kernel names through kbdm_stage_name */
+/* Block the calling thread until the critical lane of the run in flight has finished `stage` (index as in
+ * kbdm_stage_name; first group of the plan).  Lets a host that keeps two plans in flight start the second one
+ * half a cycle after the first (bench.py), so that the throughput-bound stages of one ensemble meet the QR
+ * iteration of the other.  No reference counterpart. */
+int kbdm_plan_wait_stage(kbdm_plan* plan, int stage);
 int kbdm_plan_stage_ms(kbdm_plan* plan, float* ms, int n);
 const char* kbdm_stage_name(int stage);
 /* A plan runs its members in concurrent "lanes" (sub-batches by size, largest members in lane 0,

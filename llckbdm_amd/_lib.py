@@ -36,6 +36,7 @@ SYMBOLS = {
     "kbdm_plan_offsets": (c_int, [_P, _P, _P]),
     "kbdm_plan_upload": (c_int, [_P, _P]),
     "kbdm_plan_execute": (c_int, [_P]),
+    "kbdm_plan_wait_stage": (c_int, [_P, c_int]),
     "kbdm_plan_sync": (c_int, [_P]),
     "kbdm_plan_download": (c_int, [_P, _P, _P, _P, _P, _P]),
     "kbdm_plan_lines_device": (_P, [_P]),

@@ -713,6 +713,17 @@ int kbdm_plan_sync(kbdm_plan* pl) {
     return KBDM_OK;
 }
 
+int kbdm_plan_wait_stage(kbdm_plan* pl, int stage) {
+    if (!pl || stage < 0 || stage >= KBDM_NSTAGES) return fail(KBDM_E_INVALID, "bad stage");
+    if (!pl->timed) return KBDM_OK;
+    for (auto& ch : pl->chunks)
+        if (ch.lane == 0 && !ch.ev.empty()) {
+            HIPCHK(hipEventSynchronize(ch.ev[stage + 1]));
+            break;
+        }
+    return KBDM_OK;
+}
+
 int kbdm_plan_stage_ms(kbdm_plan* pl, float* ms, int n) {
     if (!pl || !ms) return fail(KBDM_E_INVALID, "null argument");
     HIPCHK(hipStreamSynchronize(pl->ctx->stream));

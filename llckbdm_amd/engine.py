@@ -70,6 +70,12 @@ class Plan:
     def sync(self):
         _lib.check(self.engine.lib.kbdm_plan_sync(self.handle))
 
+    def wait_stage(self, name):
+        """Block until the critical lane of the run in flight has finished stage ``name`` (e.g. ``"k_hess"``)."""
+        lib = self.engine.lib
+        names = [lib.kbdm_stage_name(i).decode() for i in range(_lib.KBDM_NSTAGES)]
+        _lib.check(lib.kbdm_plan_wait_stage(self.handle, names.index(name)))
+
     def download(self):
         lines = np.empty((self.total_lines, 4), dtype=np.float64)
         sv = np.empty(self.total_sv, dtype=np.float64)
