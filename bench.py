@@ -105,6 +105,12 @@ def main():
                     help="submit the second ensemble at once instead of when the first reaches its QR iteration")
     args = ap.parse_args()
 
+    # stdout carries exactly one line (the JSON): anything a library prints there while we run (RCCL's version
+    # banner at communicator creation, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +122,6 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         try:
             import torch
@@ -125,6 +130,12 @@ def main():
 
     from llckbdm_amd import datasets
     from llckbdm_amd.engine import Engine
+
+    def init_dist():
+        # after the solver's streams exist: the runtime hands out hardware queues in order of stream creation,
+        # and the communicator's streams (idle most of the time) should be the ones that share
+        if dist is not None:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # Ensembles in flight: every step solves one whole ensemble (its own plan, workspace and streams); a step
     # is submitted without waiting for the previous one, and a plan is waited for only when its workspace is
@@ -146,6 +157,7 @@ def main():
         engines.append(e)
         plans.append(pk)
     plan = plans[0]
+    init_dist()
     sigs0 = datasets.config2(seed=rank)[0] if args.workload == "C2" else None
     units = len(ms)
 
@@ -277,7 +289,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(sigs0[0], ms, dwell) if args.workload == "C2" else None
             except Exception as e:   # the baseline is informational; never lose the GPU number over it
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
