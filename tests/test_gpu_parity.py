@@ -318,3 +318,38 @@ def test_config5_shape_multi_voxel_grid(eng):
         k, w = canonical(got[keep_mask(got)]), canonical(O.filter_samples(want))
         assert len(k) == len(w)
         assert_lines_close(k, w, rel=1e-8, phase_abs=1e-8, what=f"C5 item {i}")
+
+
+def test_two_ensembles_in_flight_give_the_same_bits():
+    """bench.py keeps two ensembles in flight (two Engines, one plan each, submitted without waiting, the second
+    one staggered with Plan.wait_stage): contention between them must not change a bit of either result."""
+    from llckbdm_amd import datasets
+    from llckbdm_amd.engine import Engine
+    ea, eb = Engine(0), Engine(0)
+    try:
+        plans, ref = [], []
+        for k, e in enumerate((ea, eb)):
+            sigs, sig_idx, ms = datasets.config2(seed=40 + k)
+            ms = ms[::5]                                   # 31 members, m = 100..400
+            p = e.plan(sigs.shape[0], sigs.shape[1], sig_idx[::5], ms, ms, p=1, q=0.0, dwell=datasets.DWELL)
+            p.upload(sigs)
+            p.execute(sync=True)                           # alone
+            r = p.download()
+            ref.append((r.lines.copy(), r.sv.copy(), r.status.copy()))
+            plans.append(p)
+        for rounds in range(2):
+            plans[0].execute(sync=False)
+            plans[0].wait_stage("k_hess")
+            plans[1].execute(sync=False)
+            plans[0].sync()
+            plans[0].execute(sync=False)                   # overlaps the tail of plan 1
+            for p in plans:
+                p.sync()
+            for p, (lines, sv, status) in zip(plans, ref):
+                r = p.download()
+                assert np.array_equal(r.status, status)
+                assert np.array_equal(r.lines, lines)
+                assert np.array_equal(r.sv, sv)
+    finally:
+        ea.close()
+        eb.close()
