@@ -57,7 +57,7 @@ def test_svd_random_and_degenerate(hs):
 
 def test_eig_random(hs):
     rng = np.random.default_rng(2)
-    for n in (1, 2, 3, 16, 40):
+    for n in (1, 2, 3, 16, 40, 96, 130):     # 96 and 130: one and two blocked Hessenberg panels (+ k_hess_z's reference form)
         W = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
         Wf = np.asfortranarray(W)
         mu, Pm = np.zeros(n, complex), np.zeros((n, n), complex, order="F")
