@@ -235,8 +235,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    res = plan.download()
     ok = min(int((pk.download().status == 0).sum()) for pk in plans)
+
+    # the same steps one at a time (outside the timed region; reported next to the headline for comparison)
+    serial = None
+    if nfl > 1 and dist is None:
+        timed[0] = False
+        ns_ser = min(args.steps, 5)
+        ts = time.perf_counter()
+        for s in range(ns_ser):
+            plans[0].execute(sync=True)
+        ts = time.perf_counter() - ts
+        serial = {"value": units * ns_ser / ts, "ms_per_step": 1e3 * ts / ns_ser, "steps": ns_ser, "ensembles_in_flight": 1}
 
     if rank == 0:
         value = world * units * args.steps / elapsed
@@ -282,6 +292,7 @@ def main():
             "pipeline_tflops": total_fl * args.steps * world / elapsed / 1e12,
             "stage_ms": stage_ms,
             "step_latency_ms": None if latency is None else 1e3 * latency,
+            "one_ensemble_at_a_time": serial,
             "members_ok": ok,
         }
         if world == 1 and not args.no_cpu_baseline:
