@@ -24,7 +24,7 @@ import time
 # The pipeline runs on three HIP streams; torch and RCCL add their own.  With the runtime's default of four
 # hardware queues those streams would share queues (measured: 194 instead of 175 ms per step in the
 # multi-process path), so ask for eight before anything initialises HIP.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 
@@ -97,9 +97,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
-                    help="ensembles (steps) in flight at once (each has its own plan and streams; more than two "
-                         "would need more hardware queues than the runtime provides)")
+    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="ensembles (steps) in flight at once (each has its own plan and three streams; every stream "
+                         "needs a hardware queue of its own: GPU_MAX_HW_QUEUES, 16 asked for here)")
     ap.add_argument("--workload", default="C2", choices=["C2", "C3small"])
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="submit the second ensemble at once instead of when the first reaches its QR iteration")
@@ -140,7 +140,7 @@ def main():
     # Ensembles in flight: every step solves one whole ensemble (its own plan, workspace and streams); a step
     # is submitted without waiting for the previous one, and a plan is waited for only when its workspace is
     # needed again.  One ensemble alone is latency bound (a chain of one-CU-per-member kernels, most of the
-    # 256 CUs idle); two in flight overlap those chains.  `step_latency_ms` is the single-ensemble latency.
+    # 256 CUs idle); two or three in flight overlap those chains.  `step_latency_ms` is the single-ensemble latency.
     nfl = max(1, args.in_flight)
     dwell = datasets.DWELL
     engines, plans = [], []
@@ -194,10 +194,11 @@ def main():
     def step(s):
         k = s % nfl
         finish(k)
-        if timed[0] and s == 1 and nfl == 2 and args.stagger:
-            # the two pipelines have the same cycle: started together they stay in phase (panels against panels,
-            # QR iteration against QR iteration); start the second one when the first reaches its QR iteration
-            plans[0].wait_stage("k_hess")
+        if timed[0] and 1 <= s < nfl and args.stagger:
+            # the pipelines have the same cycle: started together they stay in phase (panels against panels,
+            # QR iteration against QR iteration); start each one a fraction of the cycle after the one before it
+            # (two in flight: when the first reaches its QR iteration)
+            plans[s - 1].wait_stage({2: "k_hess", 3: "k_bdsqr_sort"}.get(nfl, "k_svd_fac"))
         plans[k].execute(sync=False)
         busy[k] = True
 

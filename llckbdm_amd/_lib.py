@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libkbdm_hip.so")
 # onto four hardware queues by default; once torch / RCCL streams are added they would share queues, which
 # serialises the lanes.  Effective only if HIP has not been initialised in this process yet; never overrides the
 # user's own setting.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 KBDM_ABI_VERSION = 1
 KBDM_NSTAGES = 16
