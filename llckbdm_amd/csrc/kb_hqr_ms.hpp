@@ -327,6 +327,7 @@ KB_HD int hqr_win_scratch_bytes(int nsmax, int W, int ws) {
 struct HPlain {
     cd* H;
     int ld;
+    int nc = 0;     // columns (needed only where a bounds-checked buffer view is built: kb_hqr2.hpp)
     KB_HD cd get(int r, int c) const { return H[r + (size_t)c * ld]; }
     KB_HD void put(int r, int c, cd v) const { H[r + (size_t)c * ld] = v; }
 };

@@ -83,6 +83,9 @@ struct kbdm_ctx {
     int hqr_wgs = -1;     // workgroups of the solo k_hqr launch (members are taken from a queue, largest first):
                           // -1 = as many as the launch's work needs to last no longer than its largest member,
                           // 0 = one workgroup per member, N = fixed
+    int hqr_v = 2;        // QR iteration: 2 = kb_hqr2.hpp (double-shift bulges, systolic strips), 1 = round-1 kernels
+    int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
+    int win_hqr2 = 56;    // its LDS window
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
 };
@@ -141,6 +144,8 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     return KBDM_OK;
 }
@@ -264,7 +269,8 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_iwork, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
     HIPCHK(hipMemset(pl->d_iwork, 0, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
     HIPCHK(hipMalloc(&pl->d_team, sizeof(TeamCtl) * std::max(B, 1)));
-    HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS * team_rec_bytes(pl->ctx->ns_hqr, std::max(pl->ctx->win_hqr, 8))));
+    HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS *
+                                       std::max(team_rec_bytes(pl->ctx->ns_hqr, std::max(pl->ctx->win_hqr, 8)), team2_rec_bytes(pl->ctx->win_hqr2))));
     HIPCHK(hipMalloc(&pl->d_rot, sizeof(Rot) * std::max<size_t>(pl->rot_elems, 1)));
     HIPCHK(hipMalloc(&pl->d_hdr, sizeof(RotBatch) * std::max<size_t>(pl->hdr_elems, 1)));
     if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
@@ -411,9 +417,11 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { r = tm->mark(); if (r) return r; }      // k_gen(Qh) slot (overlapped with k_hqr)
     }
     {
-        int win = ctx->win_hqr;
-        int sm = KB_RED_BYTES + (win > 0 ? hqr_win_scratch_bytes(ctx->ns_hqr, win, 64) : hqr_ms_scratch_bytes(ctx->ns_hqr));
-        if (sm > LDS_MAX - 64) {   // window does not fit LDS with this many shifts: unblocked chase
+        const bool v2 = ctx->hqr_v >= 2;
+        int win = v2 ? ctx->win_hqr2 : ctx->win_hqr;
+        int sm = v2 ? KB_RED_BYTES + hqr2_scratch_bytes(win)
+                    : KB_RED_BYTES + (win > 0 ? hqr_win_scratch_bytes(ctx->ns_hqr, win, 64) : hqr_ms_scratch_bytes(ctx->ns_hqr));
+        if (!v2 && sm > LDS_MAX - 64) {   // window does not fit LDS with this many shifts: unblocked chase
             win = 0;
             sm = KB_RED_BYTES + hqr_ms_scratch_bytes(ctx->ns_hqr);
         }
@@ -433,6 +441,10 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             while (nteam < ch.count && nteam < cap && pl->items[pl->perm[ch.first + nteam]].l >= ctx->team_min_l) ++nteam;
         }
         if (nteam > 0) {
+            if (v2)
+                hipLaunchKernelGGL(k_hqr2_team, dim3(2 * nteam), dim3(512), sm, st, pl->d_items, perm, pl->d_arena,
+                                   pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, pl->d_team, pl->d_rings, prof);
+            else
             hipLaunchKernelGGL(k_hqr_team, dim3(2 * nteam), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
                                pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, pl->d_team, pl->d_rings, prof);
         }
@@ -457,6 +469,10 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                 if (nwg > 192) nwg = 0;
             }
             int* queue = (nwg > 0 && nsolo > nwg && cidx < KB_QUEUE_WORDS) ? pl->d_iwork + 4 * pl->B + cidx : nullptr;
+            if (v2)
+                hipLaunchKernelGGL(k_hqr2, dim3(queue ? nwg : nsolo), dim3(512), sm, ss, pl->d_items, perm + nteam,
+                                   pl->d_arena, pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, prof, nsolo, queue);
+            else
             hipLaunchKernelGGL(k_hqr, dim3(queue ? nwg : nsolo), dim3(ctx->nt_hqr), sm, ss, pl->d_items, perm + nteam,
                                pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof, nsolo, queue);
             if (nteam > 0) HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));   // the join now covers Qh and the solo members
@@ -466,10 +482,10 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipMemcpy(h.data(), prof, sizeof(MsStats) * pl->B, hipMemcpyDeviceToHost));
             const MsStats& x = h[pl->perm[ch.first]];
-            fprintf(stderr, "[k_hqr prof] n=%d batches=%lld intervals=%lld winsteps=%lld singles=%lld | Mcycles: total=%.1f scan=%.1f shift=%.1f load=%.1f chase=%.1f store=%.1f strip=%.1f single=%.1f | wave0 tiles=%lld tload=%.1f treplay=%.1f tstore=%.1f\n",
+            fprintf(stderr, "[k_hqr prof] n=%d batches=%lld intervals=%lld winsteps=%lld singles=%lld | Mcycles: total=%.1f scan=%.1f shift=%.1f load=%.1f chase=%.1f store=%.1f strip=%.1f single=%.1f | wave0 tiles=%.1f tload=%.1f treplay=%.1f tstore=%.1f\n",
                     pl->items[pl->perm[ch.first]].l, x.batches, x.intervals, x.small_steps, x.single_sweeps, x.cyc_total / 1e6,
                     x.cyc_scan / 1e6, x.cyc_shift / 1e6, x.cyc_load / 1e6, x.cyc_chase / 1e6, x.cyc_store / 1e6,
-                    x.cyc_strip / 1e6, x.cyc_single / 1e6, x.ntiles, x.cyc_tload / 1e6, x.cyc_treplay / 1e6, x.cyc_tstore / 1e6);
+                    x.cyc_strip / 1e6, x.cyc_single / 1e6, x.ntiles / 1e6, x.cyc_tload / 1e6, x.cyc_treplay / 1e6, x.cyc_tstore / 1e6);
             hipFree(prof);
         }
         if (tm) { int r = tm->mark(); if (r) return r; }
@@ -599,6 +615,9 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->nt_invit = env_int("KBDM_NT_INVIT", c->nt_invit);
     c->ns_hqr = env_int("KBDM_NS_HQR", c->ns_hqr);
     c->win_hqr = env_int("KBDM_WIN_HQR", c->win_hqr);
+    c->hqr_v = env_int("KBDM_HQR_V", c->hqr_v);
+    c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
+    c->win_hqr2 = std::min(64, std::max(3 * c->nb_hqr2 + 8, env_int("KBDM_WIN_HQR2", c->win_hqr2)));
     if (c->ns_hqr > KB_MS_NSMAX) c->ns_hqr = KB_MS_NSMAX;
     if (c->win_hqr > 0 && c->win_hqr < 3 * c->ns_hqr + 8) c->win_hqr = 3 * c->ns_hqr + 8;
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));

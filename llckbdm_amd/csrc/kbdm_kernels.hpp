@@ -23,6 +23,7 @@
 
 #include "kb_eig.hpp"
 #include "kb_hqr_ms.hpp"
+#include "kb_hqr2.hpp"
 #include "kb_svd.hpp"
 #include "kbdm_device.h"
 
@@ -665,6 +666,59 @@ __global__ void __launch_bounds__(512) k_hqr_team(const KbItem* __restrict__ ite
         if (threadIdx.x == 0 && info != 0) atomicOr(&status[item], KB_STAT_EIG_NOCONV);
     } else {
         team_helper_main(ctx, tm);
+    }
+}
+
+// Second-generation QR iteration (kb_hqr2.hpp): double-shift bulges, register-systolic strip replay, window + log
+// in LDS only (two workgroups per CU).  Same launch conventions as k_hqr / k_hqr_team.
+__global__ void __launch_bounds__(512) k_hqr2(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                   cd* arena, cd* mu_out, int* status, int smem_bytes, int nbmax,
+                                                   int win_w, MsStats* prof, int count, int* queue) {
+    const DevCtx ctx = make_ctx(smem_bytes);
+    __shared__ int info;
+    __shared__ int next;
+    for (;;) {
+        int idx = blockIdx.x;
+        if (queue) {
+            if (threadIdx.x == 0) next = atomicAdd(queue, 1);
+            __syncthreads();
+            idx = next;
+            __syncthreads();
+        }
+        if ((unsigned)idx >= (unsigned)count) break;
+        const int item = perm[idx];
+        const KbItem it = items[item];
+        cd* Hc = arena + it.off[KB_BUF_H];
+        cd* mu = mu_out + it.line_off;
+        hqr2_eigvals(ctx, it.l, Hc, it.l, mu, &info, nbmax, win_w, prof ? prof + item : nullptr);
+        if (threadIdx.x == 0 && info != 0) atomicOr(&status[item], KB_STAT_EIG_NOCONV);
+        if (!queue) break;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(512) k_hqr2_team(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                        cd* arena, cd* mu_out, int* status, int smem_bytes, int nbmax,
+                                                        int win_w, TeamCtl* ctl, char* rings, MsStats* prof) {
+    const int team = blockIdx.x >> 1, role = blockIdx.x & 1;
+    const int item = perm[team];
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(smem_bytes);
+    cd* Hc = arena + it.off[KB_BUF_H];
+    Team2<DevCtx> tm;
+    tm.ctl = ctl + item;
+    tm.rec_bytes = team2_rec_bytes(win_w);
+    tm.ring = rings + (size_t)item * KB_TEAM_SLOTS * tm.rec_bytes;
+    tm.g = 0; tm.g_batch = 0; tm.failed = 0;
+    tm.A = HSc1::make(Hc, it.l, it.l);
+    tm.W = win_w;
+    if (role == 0) {
+        cd* mu = mu_out + it.line_off;
+        __shared__ int info;
+        hqr2_eigvals(ctx, it.l, Hc, it.l, mu, &info, nbmax, win_w, prof ? prof + item : nullptr, &tm);
+        if (threadIdx.x == 0 && info != 0) atomicOr(&status[item], KB_STAT_EIG_NOCONV);
+    } else {
+        team2_helper_main(ctx, tm);
     }
 }
 

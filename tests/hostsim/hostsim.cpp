@@ -13,6 +13,7 @@
 
 #include "kb_eig.hpp"
 #include "kb_hqr_ms.hpp"
+#include "kb_hqr2.hpp"
 #include "kb_svd.hpp"
 
 using namespace kb;
@@ -222,6 +223,37 @@ int hs_eigvals_team(const double* W_in, int n, int nsmax, int win_w, double* mu_
     if (stats_out) {
         stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps;
         stats_out[4] = ctl.published; stats_out[5] = ctl.all_done; stats_out[6] = ctl.done; stats_out[7] = ctl.near_done;
+    }
+    return info;
+}
+
+// Second-generation QR iteration (kb_hqr2.hpp): double-shift bulges, time-major log, strip units.
+// team != 0 runs the chase-workgroup / helper-workgroup split with the helper's share inline.
+int hs_eigvals2(const double* W_in, int n, int nbmax, int win_w, int team, double* mu_out, long long* stats_out, int smode) {
+    std::vector<cd> W(n * n), Hc(n * n), th(n);
+    memcpy(W.data(), W_in, sizeof(cd) * n * n);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr2_scratch_bytes(win_w));
+    gehd2(ctx, n, W.data(), n, th.data());
+    hess_copy(ctx, n, W.data(), n, Hc.data(), n);
+    int info = 0;
+    MsStats st;
+    memset(&st, 0, sizeof(st));
+    TeamCtl ctl;
+    memset(&ctl, 0, sizeof(ctl));
+    Team2<HostCtx> tm;
+    tm.ctl = &ctl;
+    tm.rec_bytes = team2_rec_bytes(win_w);
+    std::vector<char> ring((size_t)KB_TEAM_SLOTS * tm.rec_bytes);
+    tm.ring = ring.data();
+    tm.g = 0; tm.g_batch = 0; tm.failed = 0;
+    tm.A = HSc1::make(Hc.data(), n, n);
+    tm.W = win_w;
+    hqr2_eigvals(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nbmax, win_w, &st, team ? &tm : nullptr, smode);
+    if (stats_out) {
+        stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps;
+        stats_out[4] = ctl.published; stats_out[5] = ctl.all_done; stats_out[6] = ctl.done; stats_out[7] = ctl.near_done;
+        stats_out[8] = st.ab_calls; stats_out[9] = st.ab_fail; stats_out[10] = st.ab_iters;
     }
     return info;
 }
