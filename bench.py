@@ -7,13 +7,23 @@ sigma=1e-3 noise, members m = 100..400 step 2 (151 solves), l = m, p = 1, q = 0.
 One "step" = one pass of the whole pipeline (Hankel -> SVD -> reduced eig -> line lists) over
 that batch, signals already resident in HBM, line lists left in HBM.  With N > 1 every rank
 solves its own ensemble (another noise seed: weak scaling, members are independent) and the
-packed line lists are gathered to every rank with ONE RCCL all_gather inside the timed region.
+packed results are gathered to every rank with ONE grouped RCCL transfer (kbdm_plan_gather of the
+C ABI: device buffers to device buffers over xGMI) inside the timed region.  `--sharded` instead
+deals ONE ensemble (default C4: 1001 members, N=4096) over the ranks (strong scaling, the
+partition of llckbdm_amd.distributed.shard_items) with the same gather.  torch.distributed is the
+process launcher and the control plane only (gloo: barrier, max over ranks, id hand-off).
+`python bench.py --gpus N` without a launcher starts its own ranks (torch.distributed.run).
 
 The JSON line also carries
   roofline     : the dominant kernel's algorithmic FP64 flops / its HIP-event duration vs the
                  FP64 matrix peak (flop model: SURVEY.md 8d, stated in DESIGN.md)
   cpu_baseline : the numpy/scipy oracle (the reference's own LAPACK calls) timed on the host
-                 cores of this box on a bounded sample of the same workload (rank 0, N=1 only).
+                 cores of this box on a bounded sample of the same workload (rank 0, N=1 only):
+                 one process per core (best effort) and, as `serial`, the shape the reference ships
+                 (sampling.py:52-62: one loop, default BLAS threads).
+  host_inclusive : the same ensemble from host signals to host line lists (plan reused: H2D +
+                 execute + D2H), SURVEY.md 8d's wording of the metric.
+  north_star_workload : the m = 100..500 ensemble BASELINE.json's target is quoted on.
 """
 import argparse
 import json
@@ -91,6 +101,35 @@ def cpu_baseline(sig, ms, dwell, min_seconds=12.0, max_passes=8):
                       f"1 BLAS thread each, {dt:.1f} s wall"}
 
 
+def cpu_baseline_serial(sig, ms, dwell, stride=5):
+    """SURVEY.md 8d mode (i): the loop as the reference ships it (sampling.py:52-62): one process, members one
+    after the other, default BLAS threading - on every `stride`-th member of the workload."""
+    from oracle import kbdm_oracle as O
+    members = [int(m) for m in ms][::stride]
+    O.kbdm(sig, dwell, m=32, normalizer="gemm")
+    t0 = time.perf_counter()
+    for m in members:
+        O.kbdm(sig, dwell, m=m, normalizer="gemm")
+    dt = time.perf_counter() - t0
+    return {"value": len(members) / dt, "unit": "solves/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"every {stride}th member of the workload ({len(members)} solves) in one serial loop with default "
+                      f"BLAS threads, as sampling.py:52-62 ships it, {dt:.1f} s wall"}
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as child processes (never re-exec this one:
+    nothing here has touched the GPU yet, but a child keeps the contract simple) and forward rank 0's line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,10 +139,18 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="ensembles (steps) in flight at once (each has its own plan and three streams; every stream "
                          "needs a hardware queue of its own: GPU_MAX_HW_QUEUES, 16 asked for here)")
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3small"])
+    ap.add_argument("--workload", default=None, choices=["C2", "NS", "C3small", "C4"],
+                    help="C2 (default), NS = north-star ensemble m=100..500, C3small, C4 (default of --sharded)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="strong scaling: ONE ensemble dealt over the ranks (shard_items) + the RCCL gather per step")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / north_star_workload")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="submit the second ensemble at once instead of when the first reaches its QR iteration")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "C4" if args.sharded else "C2"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
 
     # stdout carries exactly one line (the JSON): anything a library prints there while we run (RCCL's version
     # banner at communicator creation, for one) goes to stderr
@@ -118,24 +165,33 @@ def main():
     torch = None
     # KBDM_BENCH_FORCE_DIST=1: take the multi-process path (RCCL init, device-side gather) even with one rank -
     # a rehearsal of the N > 1 code on a one-GPU box
-    if world > 1 or args.gpus > 1 or os.environ.get("KBDM_BENCH_FORCE_DIST") == "1":
+    force_dist = os.environ.get("KBDM_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-    else:
-        try:
-            import torch
-        except Exception:
-            torch = None
 
     from llckbdm_amd import datasets
     from llckbdm_amd.engine import Engine
 
+    comm_box = [None]
+
     def init_dist():
         # after the solver's streams exist: the runtime hands out hardware queues in order of stream creation,
-        # and the communicator's streams (idle most of the time) should be the ones that share
-        if dist is not None:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # and the communicator's streams (idle most of the time) should be the ones that share.  torch.distributed
+        # (gloo, CPU) is the control plane; the data path is the library's own RCCL communicator.
+        if dist is None:
+            return
+        if world > 1 or "MASTER_ADDR" in os.environ:
+            dist.init_process_group("gloo")
+        else:                                   # one-rank rehearsal without a launcher
+            dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        from llckbdm_amd.distributed import RcclComm
+
+        def exchange(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm_box[0] = RcclComm(engines[0], world, rank, exchange, force=True)
 
     # Ensembles in flight: every step solves one whole ensemble (its own plan, workspace and streams); a step
     # is submitted without waiting for the previous one, and a plan is waited for only when its workspace is
@@ -143,34 +199,53 @@ def main():
     # 256 CUs idle); two or three in flight overlap those chains.  `step_latency_ms` is the single-ensemble latency.
     nfl = max(1, args.in_flight)
     dwell = datasets.DWELL
-    engines, plans = [], []
-    for k in range(nfl):
+    from llckbdm_amd.distributed import packed_bytes, shard_items
+
+    def workload(seed):
         if args.workload == "C2":
-            sigs, sig_idx, ms = datasets.config2(seed=rank + 1000 * k)
-            wname = "C2: N=2048, 16 peaks + sigma=1e-3 noise, m=100..400:2 (151 members), l=m, p=1, q=0"
+            return datasets.config2(seed=seed) + ("C2: N=2048, 16 peaks + sigma=1e-3 noise, m=100..400:2 (151 members), l=m, p=1, q=0",)
+        if args.workload == "NS":
+            return datasets.north_star(seed=seed) + ("NS: N=2048, 16 peaks + sigma=1e-3 noise, m=100..500:2 (201 members), l=m, p=1, q=0",)
+        if args.workload == "C4":
+            return datasets.config4() + ("C4: N=4096, 32 peaks + sigma=1e-3 noise, m=200..1200 (1001 members), l=m, p=1, q=0",)
+        return datasets.config3(count=64, m=512, seed0=seed) + ("C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512",)
+
+    engines, plans, gather_sizes = [], [], []
+    for k in range(nfl):
+        if args.sharded:
+            # ONE ensemble per step, its members dealt over the ranks (every rank derives the same table)
+            sigs, sig_idx, ms_all, wname = workload(1000 * k)
+            parts = shard_items(ms_all.astype(np.float64) ** 3, world)
+            mine = parts[rank]
+            ms, sidx = ms_all[mine], sig_idx[mine]
+            gather_sizes.append(np.array([packed_bytes(ms_all[ix].sum(), ms_all[ix].sum(), len(ix)) for ix in parts],
+                                         dtype=np.int64))
+            units = len(ms_all)
         else:
-            sigs, sig_idx, ms = datasets.config3(count=64, m=512, seed0=1000 * rank + 100000 * k)
-            wname = "C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512"
+            sigs, sidx, ms, wname = workload(rank + 1000 * k)
+            gather_sizes.append(np.array([packed_bytes(ms.sum(), ms.sum(), len(ms))] * world, dtype=np.int64))
+            units = len(ms)
         e = Engine(local_rank)
-        pk = e.plan(sigs.shape[0], sigs.shape[1], sig_idx, ms, ms, p=1, q=0.0, dwell=dwell)
+        pk = e.plan(sigs.shape[0], sigs.shape[1], sidx, ms, ms, p=1, q=0.0, dwell=dwell)
         pk.upload(sigs)
         engines.append(e)
         plans.append(pk)
     plan = plans[0]
     init_dist()
-    sigs0 = datasets.config2(seed=rank)[0] if args.workload == "C2" else None
-    units = len(ms)
-
-    gather_buf = local_buf = None
+    comms = []
     if dist is not None:
-        local_buf = torch.empty((plan.total_lines, 4), dtype=torch.float64, device="cuda")
-        gather_buf = torch.empty((world * plan.total_lines, 4), dtype=torch.float64, device="cuda")
+        from llckbdm_amd.distributed import RcclComm
+
+        def exchange(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comms = [comm_box[0]] + [RcclComm(engines[k], world, rank, exchange, force=True) for k in range(1, nfl)]
+    sigs0 = workload(rank)[0] if args.workload in ("C2", "NS") else None
 
     def sync_all():
         for pk in plans:
             pk.sync()
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
 
     stage_acc = {}
     busy = [False] * nfl
@@ -182,8 +257,8 @@ def main():
             return
         pk = plans[k]
         if dist is not None:
-            pk.copy_lines_to_device(local_buf.data_ptr(), local_buf.numel() * 8)   # syncs the plan's stream
-            dist.all_gather_into_tensor(gather_buf, local_buf)
+            # the one collective of the path: every rank's packed block, device to device (waits for the plan)
+            comms[k].engine.lib.kbdm_plan_gather(pk.handle, world, rank, gather_sizes[k].ctypes.data, -1, None)
         if timed[0]:
             for name, v in pk.stage_ms().items():      # HIP events of the critical lane (waits for the plan)
                 stage_acc[name] = stage_acc.get(name, 0.0) + v
@@ -232,25 +307,72 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ok = min(int((pk.download().status == 0).sum()) for pk in plans)
+    if dist is not None and world == 1:
+        # one-rank rehearsal: the gathered block must be exactly the plan's results
+        from llckbdm_amd.distributed import unpack_block
+        buf = comms[0].gather_plan(plans[0], gather_sizes[0])
+        ref = plans[0].download()
+        ll, sv, st, kp = unpack_block(buf, plans[0].total_lines, plans[0].total_sv, plans[0].B)
+        assert np.array_equal(ll, ref.lines) and np.array_equal(sv, ref.sv) and np.array_equal(kp, ref.keep.astype(bool))
 
     # the same steps one at a time (outside the timed region; reported next to the headline for comparison)
-    serial = None
-    if nfl > 1 and dist is None:
+    serial = host_incl = ns_line = None
+    if dist is None:
         timed[0] = False
         ns_ser = min(args.steps, 5)
-        ts = time.perf_counter()
-        for s in range(ns_ser):
-            plans[0].execute(sync=True)
-        ts = time.perf_counter() - ts
-        serial = {"value": units * ns_ser / ts, "ms_per_step": 1e3 * ts / ns_ser, "steps": ns_ser, "ensembles_in_flight": 1}
+        if nfl > 1:
+            ts = time.perf_counter()
+            for s in range(ns_ser):
+                plans[0].execute(sync=True)
+            ts = time.perf_counter() - ts
+            serial = {"value": units * ns_ser / ts, "ms_per_step": 1e3 * ts / ns_ser, "steps": ns_ser, "ensembles_in_flight": 1}
+        if not args.no_extras:
+            # SURVEY.md 8d's wording of the metric: host signals resident -> host line lists resident, with the plan
+            # (device workspace) reused as Engine.solve does for a repeated geometry
+            sig_host = np.ascontiguousarray(workload(rank)[0])
+            th = time.perf_counter()
+            for s in range(ns_ser):
+                plans[0].upload(sig_host)
+                plans[0].execute(sync=False)
+                plans[0].download()
+            th = time.perf_counter() - th
+            host_incl = {"value": units * ns_ser / th, "unit": "solves/s", "ms_per_step": 1e3 * th / ns_ser, "steps": ns_ser,
+                         "ensembles_in_flight": 1, "includes": "H2D of the signal + execute + D2H of lines, sv, mu, keep, status"}
+            if args.workload == "C2" and not args.sharded:
+                # the ensemble the north-star target is quoted on (m = 100..500), same number of ensembles in flight
+                for pk in plans[1:]:
+                    pk.close()
+                ns_plans = []
+                for k in range(nfl):
+                    sg, si, mm = datasets.north_star(seed=rank + 1000 * k)
+                    pk = engines[k].plan(1, sg.shape[1], si, mm, mm, p=1, q=0.0, dwell=dwell)
+                    pk.upload(sg)
+                    pk.execute(sync=True)
+                    ns_plans.append(pk)
+                nst = max(nfl, min(args.steps, 2 * nfl))
+                tn = time.perf_counter()
+                for s in range(nst):
+                    if s >= nfl:
+                        ns_plans[s % nfl].sync()
+                    ns_plans[s % nfl].execute(sync=False)
+                for pk in ns_plans:
+                    pk.sync()
+                tn = time.perf_counter() - tn
+                t1 = time.perf_counter()
+                ns_plans[0].execute(sync=True)
+                t1 = time.perf_counter() - t1
+                ns_ok = int((ns_plans[0].download().status == 0).sum())
+                ns_line = {"workload": "N=2048, 16 peaks + sigma=1e-3 noise, m=100..500:2 (201 members)",
+                           "value": len(mm) * nst / tn, "unit": "solves/s", "ms_per_step": 1e3 * tn / nst, "steps": nst,
+                           "ensembles_in_flight": nfl, "one_ensemble_at_a_time": len(mm) / t1, "members_ok": ns_ok}
 
     if rank == 0:
-        value = world * units * args.steps / elapsed
+        value = (1 if args.sharded else world) * units * args.steps / elapsed
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
         # stage timers are those of lane 0 (the largest members, the critical path): price its launches
         # with the flops of exactly those members; `pipeline_tflops` below uses all members
@@ -265,45 +387,67 @@ def main():
                 fl_all[k] = fl_all.get(k, 0.0) + v
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/), if any
-        traffic = None
+        # the kernel behind the dominant stage timer (lane 0 runs the QR iteration as the team kernel)
+        hqr_v2 = os.environ.get("KBDM_HQR_V", "2") != "1"
+        kname = {"k_hqr": "k_hqr2_team" if hqr_v2 else "k_hqr_team", "k_svd_fac": "k_bidiag_panel", "k_hess": "k_hess_panel",
+                 "k_gen(Q,P)": "k_gen<8>", "k_bdsqr_apply": "k_bdsqr_stream", "k_invit": "k_invit_reg<8>"}.get(dom, dom)
+        # HBM bytes per launch of that kernel: NOT measured by this run - taken from the newest committed PMC passes
+        # (profiles/*_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command), if any
+        traffic = traffic_src = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_last_pmc_traffic.json")))["kernels"]
-            # lane 0 runs the QR iteration as k_hqr_team; k_gen is templated on the register chunk count
-            for key in (dom + "_team", dom, dom.split("(")[0], dom.split("(")[0] + "<8>"):
-                if key in pmc:
-                    traffic = pmc[key].get("hbm_bytes_per_launch")
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                pmc = json.load(open(fn))["kernels"]
+                if kname in pmc:
+                    traffic = pmc[kname].get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/" + os.path.basename(fn) + " (committed rocprofv3 PMC passes, not this run)"
                     break
         except Exception:
             traffic = None
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+        roofline = {"kernel": kname, "stage_timer": dom,
+                    "bound": "mfma" if kname in ("k_trail_update", "k_hess_update") else "fp64_vector",
+                    "bound_note": "FP64 vector FMA, instruction-issue / latency bound (no MFMA in this kernel); "
+                                  "MI355X FP64 vector peak = FP64 matrix peak = 78.6 TFLOP/s",
+                    "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_ms": stage_ms[dom], "algorithmic_flops_per_launch": fl[dom],
                     "launch_members": n0}
         total_fl = sum(fl_all.values())
         out = {
             "metric": "KBDM solves/sec over m-range ensemble, N=2048 complex signal",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if args.sharded else "weak",
             "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
-            "config": {"workload": wname, "members_per_gpu": units, "parallelism": f"ensemble-sharded x{world}",
+            "config": {"workload": wname, "members_per_gpu": len(ms), "members_per_step": units * (1 if args.sharded else world),
+                       "parallelism": (f"one ensemble sharded over {world} rank(s) by LPT on m^3" if args.sharded
+                                       else f"one ensemble per rank x{world}"),
                        "ensembles_in_flight": nfl,
-                       "collective": "one all_gather of packed line lists (RCCL)" if world > 1 else "none"},
+                       "collective": ("one grouped RCCL send/recv of the packed results per step (kbdm_plan_gather)"
+                                      if dist is not None else "none")},
             "roofline": roofline,
             "pipeline_tflops": total_fl * args.steps * world / elapsed / 1e12,
             "stage_ms": stage_ms,
             "step_latency_ms": None if latency is None else 1e3 * latency,
             "one_ensemble_at_a_time": serial,
+            "host_inclusive": host_incl,
+            "north_star_workload": ns_line,
             "members_ok": ok,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and dist is None and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(sigs0[0], ms, dwell) if args.workload == "C2" else None
+                if args.workload in ("C2", "NS"):
+                    out["cpu_baseline"] = cpu_baseline(sigs0[0], ms, dwell)
+                    out["cpu_baseline"]["serial"] = cpu_baseline_serial(sigs0[0], ms, dwell)
+                else:
+                    out["cpu_baseline"] = None
             except Exception as e:   # the baseline is informational; never lose the GPU number over it
                 out["cpu_baseline"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        for c in comms:
+            c.close()
         dist.destroy_process_group()
 
 

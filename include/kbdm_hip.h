@@ -96,7 +96,26 @@ const char* kbdm_stage_name(int stage);
  * critical path.  Returns the number of members (the largest ones) that lane 0 holds. */
 int kbdm_plan_lane0_members(const kbdm_plan* plan);
 
-/* One-shot: plan + upload + execute + download.  line_off/sv_off (B+1) are outputs. */
+/* ---- multi-GPU: the sharded ensemble (reference loop sampling.py:52-70, members dealt over the ranks) ends in ONE
+ * variable-length gather of every rank's packed results over xGMI.  The library binds librccl.so itself (dlopen); the
+ * context owns the communicator.  Launcher protocol: rank 0 calls kbdm_comm_unique_id and hands the 128 bytes to the
+ * other ranks by whatever means the launcher has (before any collective); every rank then calls kbdm_comm_init.
+ * A rank's packed block is  [lines: L x 4 f64][sv: SV f64][status: B i32][keep: L u8][pad to 16 B]  for its L lines,
+ * SV singular values and B members; kbdm_packed_bytes gives its size, so every rank can size every other rank's block
+ * from the (deterministic) shard table alone: no size exchange, no host bounce. */
+#define KBDM_UNIQUE_ID_BYTES 128
+int kbdm_comm_unique_id(unsigned char* id_out);
+int kbdm_comm_init(kbdm_ctx* ctx, int world, int rank, const unsigned char* id);
+int kbdm_comm_destroy(kbdm_ctx* ctx);
+int64_t kbdm_packed_bytes(int64_t lines, int64_t sv, int64_t members);
+/* Packs this plan's results on the device and gathers the blocks of all `world` ranks (bytes[r] = block size of rank
+ * r, blocks concatenated in rank order) with one grouped ncclSend/ncclRecv on the plan's stream: to every rank
+ * (root < 0) or to `root` only.  host_out (sum of bytes, receiving ranks; may be null) gets a copy; the device copy
+ * stays available through kbdm_gathered_device.  world == 1 needs no communicator. */
+int kbdm_plan_gather(kbdm_plan* plan, int world, int rank, const int64_t* bytes, int root, void* host_out);
+void* kbdm_gathered_device(kbdm_ctx* ctx);
+
+/* One-shot: plan + upload + execute + download. */
 int kbdm_solve_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B,
                      const int32_t* sig_idx, const int32_t* m, const int32_t* l, int p, double q,
                      double dwell, double* lines, double* sv, double* mu, uint8_t* keep,

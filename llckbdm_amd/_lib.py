@@ -19,6 +19,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 KBDM_ABI_VERSION = 1
 KBDM_NSTAGES = 16
+KBDM_UNIQUE_ID_BYTES = 128
 STAT_SVD_NOCONV, STAT_EIG_NOCONV, STAT_INVIT_WEAK = 1, 2, 4
 
 # every symbol include/kbdm_hip.h declares: (restype, argtypes)
@@ -49,6 +50,12 @@ SYMBOLS = {
     "kbdm_silhouette_samples": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "kbdm_hdbscan_sweep": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "kbdm_hdbscan_labels_from_mst": (c_int, [c_int, _P, _P, _P, c_int, _P]),
+    "kbdm_comm_unique_id": (c_int, [_P]),
+    "kbdm_comm_init": (c_int, [_P, c_int, c_int, _P]),
+    "kbdm_comm_destroy": (c_int, [_P]),
+    "kbdm_packed_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "kbdm_plan_gather": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
+    "kbdm_gathered_device": (_P, [_P]),
     "kbdm_solve_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_double, c_double,
                                  _P, _P, _P, _P, _P]),
     "kbdm_hankel_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),

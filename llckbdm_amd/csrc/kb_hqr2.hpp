@@ -922,6 +922,35 @@ __device__ __forceinline__ bool aberth16_quad(const DevCtx& c, const cd* __restr
 }
 #endif
 
+// The shift solvers are cold (once per sweep) and register hungry: kept out of line on the device so that their
+// register needs do not inflate the allocation of the chase / replay loops (two workgroups per CU need <= 128 VGPRs).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KB2_COLD __attribute__((noinline))
+#else
+#define KB2_COLD
+#endif
+template <class C>
+KB2_COLD KB_HD void hqr2_shifts(const C& ctx, int ns, cd* S, cd* sh, cd* aws, int* sinfo, MsStats* stats) {
+    WaveCtx<C> wc{ctx, nullptr, 0};
+    bool ok = false;
+    if (ns >= 3) {
+        int iters = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (ns == 16) ok = aberth16_quad(ctx, S, sh, aws, 60, &iters);
+#else
+        if (ns == 16) ok = aberth_eigs(wc, ns, S, ns, sh, aws, aws + ns * ns, aws + 2 * ns * ns, 60);
+#endif
+        else if (ns == 8) ok = aberth_eigs_reg<8>(wc, S, ns, sh, aws, 40, &iters);
+        else ok = aberth_eigs(wc, ns, S, ns, sh, aws, aws + ns * ns, aws + 2 * ns * ns, 60);
+        if (stats && ctx.tid() == 0) { stats->ab_calls++; stats->ab_iters += iters; if (!ok) stats->ab_fail++; }
+    }
+    if (!ok) hqr_eigvals(wc, ns, S, ns, sh, sinfo);
+}
+template <class C>
+KB2_COLD KB_HD void hqr2_single_sweep(const C& ctx, cd* H, int ld, int l, int i, int kdefl) {
+    single_shift_sweep(ctx, H, ld, l, i, kdefl);
+}
+
 // ---- driver: deflation scan, shifts, sweeps (the structure of hqr_eigvals_ms; nb bulges = 2 nb shifts per sweep)
 template <class C>
 KB_HD void hqr2_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info, int nbmax, int win_w,
@@ -998,7 +1027,7 @@ KB_HD void hqr2_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info, in
             kdefl++;
             if (na < KB2_MS_MIN) {
                 const long long c0 = KB_CLOCK();
-                single_shift_sweep(ctx, H, ld, l, i, kdefl);
+                hqr2_single_sweep(ctx, H, ld, l, i, kdefl);
                 if (stats && tid == 0) { stats->single_sweeps++; stats->cyc_single += KB_CLOCK() - c0; }
             } else {
                 const long long c_sh0 = KB_CLOCK();
@@ -1020,22 +1049,7 @@ KB_HD void hqr2_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info, in
                         S[r + c * ns] = (r <= c + 1) ? HH(r0 + r, r0 + c) : czero();
                     }
                     ctx.sync();
-                    if (ctx.wave() == 0) {
-                        WaveCtx<C> wc{ctx, nullptr, 0};
-                        bool ok = false;
-                        if (ns >= 3) {
-                            int iters = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-                            if (ns == 16) ok = aberth16_quad(ctx, S, sh, aws, 60, &iters);
-#else
-                            if (ns == 16) ok = aberth_eigs(wc, ns, S, ns, sh, aws, aws + ns * ns, aws + 2 * ns * ns, 60);
-#endif
-                            else if (ns == 8) ok = aberth_eigs_reg<8>(wc, S, ns, sh, aws, 40, &iters);
-                            else ok = aberth_eigs(wc, ns, S, ns, sh, aws, aws + ns * ns, aws + 2 * ns * ns, 60);
-                            if (stats && tid == 0) { stats->ab_calls++; stats->ab_iters += iters; if (!ok) stats->ab_fail++; }
-                        }
-                        if (!ok) hqr_eigvals(wc, ns, S, ns, sh, sinfo);
-                    }
+                    if (ctx.wave() == 0) hqr2_shifts(ctx, ns, S, sh, aws, sinfo, stats);
                 }
                 ctx.sync();
                 if (smode == 1) {

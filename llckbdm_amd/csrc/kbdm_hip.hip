@@ -3,6 +3,7 @@
 // the kernels of kbdm_kernels.hpp on one HIP stream and moves results.  No CPU compute path
 // exists here: without a gfx950 device every entry point fails with KBDM_E_NODEVICE/HIP.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -36,6 +37,28 @@ int fail(int code, const std::string& msg) {
         if (e__ != hipSuccess)                                                              \
             return fail(KBDM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
     } while (0)
+
+// inside a `do { ... } while (0)` block with an `int r`: record the failure and leave the block (cleanup follows it)
+#define HIPTRY(expr)                                                                        \
+    {                                                                                       \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            r = fail(KBDM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));       \
+            break;                                                                          \
+        }                                                                                   \
+    }
+
+// device allocations of a stage entry point, released on every path out of it
+struct DevBufs {
+    std::vector<void*> ptrs;
+    ~DevBufs() { for (void* p : ptrs) if (p) hipFree(p); }
+    template <class T> hipError_t alloc(T** out, size_t bytes) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) { ptrs.push_back(p); *out = static_cast<T*>(p); }
+        return e;
+    }
+};
 
 int env_int(const char* name, int def) {
     const char* v = getenv(name);
@@ -83,11 +106,19 @@ struct kbdm_ctx {
     int hqr_wgs = -1;     // workgroups of the solo k_hqr launch (members are taken from a queue, largest first):
                           // -1 = as many as the launch's work needs to last no longer than its largest member,
                           // 0 = one workgroup per member, N = fixed
+    int blocked = 1;      // blocked (panel + MFMA update) reductions; 0: unblocked kernels only (debugging)
+    int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
     int hqr_v = 2;        // QR iteration: 2 = kb_hqr2.hpp (double-shift bulges, systolic strips), 1 = round-1 kernels
     int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
     int win_hqr2 = 56;    // its LDS window
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
+    // multi-GPU: RCCL communicator (one per context) and the device buffers of the packed gather
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    char* d_pack = nullptr;
+    char* d_gather = nullptr;
+    size_t pack_cap = 0, gather_cap = 0;
 };
 
 struct Chunk {
@@ -321,7 +352,7 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     const int* perm = pl->d_perm + ch.first;
     {
         // blocked part: panels + MFMA trailing updates (all inside the "k_svd_fac" stage timer)
-        const int npan = (env_int("KBDM_BLOCKED", 1) != 0) ? bidiag_num_panels(ch.mmax) : 0;
+        const int npan = ctx->blocked ? bidiag_num_panels(ch.mmax) : 0;
         const int smp = KB_RED_BYTES + bidiag_panel_scratch_bytes(ch.mmax, ctx->nt_fac / 64, 64);
         if (npan > 0 && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
         for (int pnl = 0; pnl < npan; ++pnl) {
@@ -366,7 +397,8 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         // Rotation replay (streaming, no LDS): one launch for the whole chunk; with the in-kernel hand-off
         // its wavefronts follow the generators set by set.
         hipLaunchKernelGGL(k_bdsqr_stream, dim3((2 * ch.mmax + 63) / 64, ch.count, 2), dim3(64), 0, st, pl->d_items,
-                           perm, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, flag_mode ? 1 : 0);
+                           perm, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, flag_mode ? 1 : 0, pl->d_status,
+                           (unsigned)std::max(1, env_int("KBDM_BDSQR_SPIN_LIMIT", 1 << 26)));
         if (flag_mode) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
@@ -386,7 +418,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     hipStream_t st = ln.stream;
     const int* perm = pl->d_perm + ch.first;
     {
-        const int npan = (env_int("KBDM_BLOCKED", 1) != 0) ? bidiag_num_panels(ch.lmax) : 0;
+        const int npan = ctx->blocked ? bidiag_num_panels(ch.lmax) : 0;
         const int smp = KB_RED_BYTES + hess_panel_scratch_bytes(ch.lmax, ctx->nt_fac / 64, 64);
         if (npan > 0 && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg panel scratch");
         for (int pnl = 0; pnl < npan; ++pnl) {
@@ -426,7 +458,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             sm = KB_RED_BYTES + hqr_ms_scratch_bytes(ctx->ns_hqr);
         }
         MsStats* prof = nullptr;
-        const bool do_prof = env_int("KBDM_HQR_PROF", 0) != 0;
+        const bool do_prof = ctx->hqr_prof != 0;
         if (do_prof) {
             HIPCHK(hipMalloc(&prof, sizeof(MsStats) * pl->B));
             HIPCHK(hipMemsetAsync(prof, 0, sizeof(MsStats) * pl->B, st));
@@ -616,6 +648,8 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->ns_hqr = env_int("KBDM_NS_HQR", c->ns_hqr);
     c->win_hqr = env_int("KBDM_WIN_HQR", c->win_hqr);
     c->hqr_v = env_int("KBDM_HQR_V", c->hqr_v);
+    c->blocked = env_int("KBDM_BLOCKED", c->blocked);
+    c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
     c->win_hqr2 = std::min(64, std::max(3 * c->nb_hqr2 + 8, env_int("KBDM_WIN_HQR2", c->win_hqr2)));
     if (c->ns_hqr > KB_MS_NSMAX) c->ns_hqr = KB_MS_NSMAX;
@@ -646,6 +680,9 @@ int kbdm_ctx_destroy(kbdm_ctx* ctx) {
         if (ln.ev_done) hipEventDestroy(ln.ev_done);
     }
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
+    if (ctx->comm) kbdm_comm_destroy(ctx);
+    if (ctx->d_pack) hipFree(ctx->d_pack);
+    if (ctx->d_gather) hipFree(ctx->d_gather);
     delete ctx;
     return KBDM_OK;
 }
@@ -794,6 +831,148 @@ int kbdm_plan_copy_lines_device(kbdm_plan* pl, void* dst, int64_t dst_bytes) {
     return KBDM_OK;
 }
 
+// ---- RCCL, bound at run time (the library loads and solves without it; only the gather of a sharded ensemble needs it)
+namespace {
+struct KbUid { char b[KBDM_UNIQUE_ID_BYTES]; };      // ncclUniqueId (passed by value)
+struct RcclApi {
+    void* so = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, KbUid, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+constexpr int kNcclUint8 = 1;
+
+int rccl_load() {
+    if (g_rccl.so) return KBDM_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* so = nullptr;
+    for (const char* n : names)
+        if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!so) return fail(KBDM_E_HIP, std::string("librccl.so not found: ") + dlerror());
+    RcclApi a;
+    a.so = so;
+    *(void**)&a.GetUniqueId = dlsym(so, "ncclGetUniqueId");
+    *(void**)&a.CommInitRank = dlsym(so, "ncclCommInitRank");
+    *(void**)&a.CommDestroy = dlsym(so, "ncclCommDestroy");
+    *(void**)&a.GroupStart = dlsym(so, "ncclGroupStart");
+    *(void**)&a.GroupEnd = dlsym(so, "ncclGroupEnd");
+    *(void**)&a.Send = dlsym(so, "ncclSend");
+    *(void**)&a.Recv = dlsym(so, "ncclRecv");
+    *(void**)&a.GetErrorString = dlsym(so, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv)
+        return fail(KBDM_E_HIP, "librccl.so lacks an expected symbol");
+    g_rccl = a;
+    return KBDM_OK;
+}
+#define NCCLCHK(expr)                                                                                       \
+    do {                                                                                                    \
+        int e__ = (expr);                                                                                   \
+        if (e__ != 0)                                                                                       \
+            return fail(KBDM_E_HIP, std::string(#expr) + ": " +                                             \
+                                        (g_rccl.GetErrorString ? g_rccl.GetErrorString(e__) : "rccl error")); \
+    } while (0)
+}  // namespace
+
+int kbdm_comm_unique_id(unsigned char* id_out) {
+    if (!id_out) return fail(KBDM_E_INVALID, "null argument");
+    int r = rccl_load();
+    if (r) return r;
+    NCCLCHK(g_rccl.GetUniqueId(id_out));
+    return KBDM_OK;
+}
+
+int kbdm_comm_init(kbdm_ctx* ctx, int world, int rank, const unsigned char* id) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return fail(KBDM_E_INVALID, "bad communicator arguments");
+    if (ctx->comm) return fail(KBDM_E_INVALID, "the context already owns a communicator");
+    int r = rccl_load();
+    if (r) return r;
+    HIPCHK(hipSetDevice(ctx->device));
+    KbUid uid;
+    memcpy(uid.b, id, KBDM_UNIQUE_ID_BYTES);
+    NCCLCHK(g_rccl.CommInitRank(&ctx->comm, world, uid, rank));
+    ctx->comm_world = world;
+    ctx->comm_rank = rank;
+    return KBDM_OK;
+}
+
+int kbdm_comm_destroy(kbdm_ctx* ctx) {
+    if (!ctx || !ctx->comm) return KBDM_OK;
+    hipStreamSynchronize(ctx->stream);
+    g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 0;
+    return KBDM_OK;
+}
+
+int64_t kbdm_packed_bytes(int64_t lines, int64_t sv, int64_t members) {
+    const int64_t raw = 32 * lines + 8 * sv + 4 * members + lines;
+    return (raw + 15) & ~(int64_t)15;
+}
+
+void* kbdm_gathered_device(kbdm_ctx* ctx) { return ctx ? ctx->d_gather : nullptr; }
+
+int kbdm_plan_gather(kbdm_plan* pl, int world, int rank, const int64_t* bytes, int root, void* host_out) {
+    if (!pl || !bytes || world < 1 || rank < 0 || rank >= world || root >= world) return fail(KBDM_E_INVALID, "bad gather arguments");
+    kbdm_ctx* ctx = pl->ctx;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t mine = kbdm_packed_bytes(pl->total_lines, pl->total_sv, pl->B);
+    if (bytes[rank] != mine) return fail(KBDM_E_INVALID, "bytes[rank] does not match this plan's packed size");
+    if ((world > 1 || ctx->comm) && (!ctx->comm || ctx->comm_world != world || ctx->comm_rank != rank))
+        return fail(KBDM_E_INVALID, "no communicator for this world size / rank: call kbdm_comm_init first");
+    int64_t total = 0;
+    std::vector<int64_t> off(world + 1, 0);
+    for (int r = 0; r < world; ++r) {
+        if (bytes[r] < 0 || (bytes[r] & 15)) return fail(KBDM_E_INVALID, "block sizes must be multiples of 16");
+        off[r + 1] = off[r] + bytes[r];
+    }
+    total = off[world];
+    if ((size_t)mine > ctx->pack_cap) {
+        if (ctx->d_pack) HIPCHK(hipFree(ctx->d_pack));
+        ctx->d_pack = nullptr; ctx->pack_cap = 0;
+        HIPCHK(hipMalloc(&ctx->d_pack, std::max<size_t>((size_t)mine, 16)));
+        ctx->pack_cap = std::max<size_t>((size_t)mine, 16);
+    }
+    if ((size_t)total > ctx->gather_cap) {
+        if (ctx->d_gather) HIPCHK(hipFree(ctx->d_gather));
+        ctx->d_gather = nullptr; ctx->gather_cap = 0;
+        HIPCHK(hipMalloc(&ctx->d_gather, std::max<size_t>((size_t)total, 16)));
+        ctx->gather_cap = std::max<size_t>((size_t)total, 16);
+    }
+    // pack on the plan's stream (ordered after the run it belongs to)
+    char* d = ctx->d_pack;
+    if (mine > 0) HIPCHK(hipMemsetAsync(d + (mine - 16), 0, 16, st));     // the padding bytes are defined
+    if (pl->total_lines) HIPCHK(hipMemcpyAsync(d, pl->d_lines, 32 * pl->total_lines, hipMemcpyDeviceToDevice, st));
+    d += 32 * pl->total_lines;
+    if (pl->total_sv) HIPCHK(hipMemcpyAsync(d, pl->d_sv, 8 * pl->total_sv, hipMemcpyDeviceToDevice, st));
+    d += 8 * pl->total_sv;
+    if (pl->B) HIPCHK(hipMemcpyAsync(d, pl->d_status, 4 * (size_t)pl->B, hipMemcpyDeviceToDevice, st));
+    d += 4 * (size_t)pl->B;
+    if (pl->total_lines) HIPCHK(hipMemcpyAsync(d, pl->d_keep, pl->total_lines, hipMemcpyDeviceToDevice, st));
+    const bool receive = root < 0 || root == rank;
+    if (world == 1 && !ctx->comm) {
+        if (mine) HIPCHK(hipMemcpyAsync(ctx->d_gather, ctx->d_pack, mine, hipMemcpyDeviceToDevice, st));
+    } else {
+        // ONE grouped operation: every block travels once, straight between device buffers
+        NCCLCHK(g_rccl.GroupStart());
+        for (int r = 0; r < world; ++r) {
+            const bool to_r = root < 0 || r == root;
+            if (to_r && mine) NCCLCHK(g_rccl.Send(ctx->d_pack, (size_t)mine, kNcclUint8, r, ctx->comm, st));
+            if (receive && bytes[r]) NCCLCHK(g_rccl.Recv(ctx->d_gather + off[r], (size_t)bytes[r], kNcclUint8, r, ctx->comm, st));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+    }
+    if (host_out && receive && total) HIPCHK(hipMemcpyAsync(host_out, ctx->d_gather, total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return KBDM_OK;
+}
+
 int kbdm_solve_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B, const int32_t* sig_idx,
                      const int32_t* m, const int32_t* l, int p, double q, double dwell, double* lines,
                      double* sv, double* mu, uint8_t* keep, int32_t* status) {
@@ -824,8 +1003,9 @@ int kbdm_hankel_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B,
     KbItem* d_items = nullptr;
     double* host_out[3] = {U0, Up1, Up};
     const int shifts[3] = {0, p - 1, p};
-    HIPCHK(hipMalloc(&d_sig, sizeof(cd) * (size_t)S * N));
-    HIPCHK(hipMalloc(&d_items, sizeof(KbItem) * B));
+    DevBufs bufs;                                   // freed on every return below
+    HIPCHK(bufs.alloc(&d_sig, sizeof(cd) * (size_t)S * N));
+    HIPCHK(bufs.alloc(&d_items, sizeof(KbItem) * std::max(B, 1)));
     HIPCHK(hipMemcpy(d_sig, signals, sizeof(cd) * (size_t)S * N, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_items, pl.items.data(), sizeof(KbItem) * B, hipMemcpyHostToDevice));
     HankelOut o[3];
@@ -833,7 +1013,7 @@ int kbdm_hankel_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B,
     int which[3];
     for (int k = 0; k < 3; ++k)
         if (host_out[k]) {
-            HIPCHK(hipMalloc(&d_out[k], sizeof(cd) * std::max<size_t>(tot, 1)));
+            HIPCHK(bufs.alloc(&d_out[k], sizeof(cd) * std::max<size_t>(tot, 1)));
             o[nout] = HankelOut{d_out[k], shifts[k], 0, 0};
             which[nout++] = k;
         }
@@ -847,9 +1027,6 @@ int kbdm_hankel_batch(kbdm_ctx* ctx, const double* signals, int S, int N, int B,
         for (int k = 0; k < nout; ++k)
             HIPCHK(hipMemcpy(host_out[which[k]], d_out[which[k]], sizeof(cd) * tot, hipMemcpyDeviceToHost));
     }
-    for (int k = 0; k < 3; ++k) hipFree(d_out[k]);
-    hipFree(d_sig);
-    hipFree(d_items);
     return KBDM_OK;
 }
 
@@ -876,30 +1053,30 @@ int kbdm_svd_batch(kbdm_ctx* ctx, const double* A, int B, const int32_t* m, doub
     hipStream_t st = ctx->stream;
     r = KBDM_OK;
     do {
-        if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
-        hipMemcpy(d_dense, A, sizeof(cd) * tot, hipMemcpyHostToDevice);
-        hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
-        hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * B + KB_QUEUE_WORDS), st);
+        HIPTRY(hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)));
+        HIPTRY(hipMemcpy(d_dense, A, sizeof(cd) * tot, hipMemcpyHostToDevice));
+        HIPTRY(hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st));
+        HIPTRY(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * B + KB_QUEUE_WORDS), st));
         for (auto& ch : pl->chunks) {
             // stage plans are built in one chunk by construction of the tests; handle generally
             hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_A, 0);
             if ((r = launch_svd(pl, ch, nullptr))) break;
         }
         if (r) break;
-        if (hipStreamSynchronize(st) != hipSuccess) { r = fail(KBDM_E_HIP, "svd stage failed"); break; }
+        HIPTRY(hipStreamSynchronize(st));
         if (L) {
             hipLaunchKernelGGL(k_transpose_out, dim3(64, B), dim3(256), 0, st, pl->d_items, pl->d_arena, KB_BUF_A, d_dense, 0);
-            hipStreamSynchronize(st);
-            hipMemcpy(L, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost);
+            HIPTRY(hipStreamSynchronize(st));
+            HIPTRY(hipMemcpy(L, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost));
         }
         if (R) {
             hipLaunchKernelGGL(k_transpose_out, dim3(64, B), dim3(256), 0, st, pl->d_items, pl->d_arena, KB_BUF_R, d_dense, 0);
-            hipStreamSynchronize(st);
-            hipMemcpy(R, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost);
+            HIPTRY(hipStreamSynchronize(st));
+            HIPTRY(hipMemcpy(R, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost));
         }
-        if (s) hipMemcpy(s, pl->d_sv, sizeof(double) * pl->total_sv, hipMemcpyDeviceToHost);
-        if (status) hipMemcpy(status, pl->d_status, sizeof(int) * B, hipMemcpyDeviceToHost);
-        if (hipGetLastError() != hipSuccess) r = fail(KBDM_E_HIP, "svd stage copy failed");
+        if (s) HIPTRY(hipMemcpy(s, pl->d_sv, sizeof(double) * pl->total_sv, hipMemcpyDeviceToHost));
+        if (status) HIPTRY(hipMemcpy(status, pl->d_status, sizeof(int) * B, hipMemcpyDeviceToHost));
+        HIPTRY(hipGetLastError());
     } while (0);
     hipFree(d_dense);
     if (pl->chunks.size() > 1) r = fail(KBDM_E_NOMEM, "stage API batch exceeds the workspace budget");
@@ -924,22 +1101,22 @@ int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, doub
     hipStream_t st = ctx->stream;
     do {
         if (pl->chunks.size() > 1) { r = fail(KBDM_E_NOMEM, "stage API batch exceeds the workspace budget"); break; }
-        if (hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)) != hipSuccess) { r = fail(KBDM_E_HIP, "hipMalloc"); break; }
-        hipMemcpy(d_dense, W, sizeof(cd) * tot, hipMemcpyHostToDevice);
-        hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st);
-        hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * B + KB_QUEUE_WORDS), st);     // member-queue counters
-        hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * B, st);
+        HIPTRY(hipMalloc(&d_dense, sizeof(cd) * std::max<size_t>(tot, 1)));
+        HIPTRY(hipMemcpy(d_dense, W, sizeof(cd) * tot, hipMemcpyHostToDevice));
+        HIPTRY(hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st));
+        HIPTRY(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * B + KB_QUEUE_WORDS), st));     // member-queue counters
+        HIPTRY(hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * B, st));
         Chunk& ch = pl->chunks[0];
         hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_P, 1);
         hipLaunchKernelGGL(k_fill_ones, dim3(B), dim3(256), 0, st, pl->d_items, pl->d_varena);
         if ((r = launch_eig(pl, ch, nullptr))) break;
         launch_gemm<3>(pl, ch, ch.lmax, ch.lmax);   // P = Qh X (Dsqi = 1)
         hipLaunchKernelGGL(k_transpose_out, dim3(64, B), dim3(256), 0, st, pl->d_items, pl->d_arena, KB_BUF_P, d_dense, 1);
-        if (hipStreamSynchronize(st) != hipSuccess) { r = fail(KBDM_E_HIP, "eig stage failed"); break; }
-        if (P) hipMemcpy(P, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost);
-        if (mu) hipMemcpy(mu, pl->d_mu, sizeof(cd) * pl->total_lines, hipMemcpyDeviceToHost);
-        if (status) hipMemcpy(status, pl->d_status, sizeof(int) * B, hipMemcpyDeviceToHost);
-        if (hipGetLastError() != hipSuccess) r = fail(KBDM_E_HIP, "eig stage copy failed");
+        HIPTRY(hipStreamSynchronize(st));
+        if (P) HIPTRY(hipMemcpy(P, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost));
+        if (mu) HIPTRY(hipMemcpy(mu, pl->d_mu, sizeof(cd) * pl->total_lines, hipMemcpyDeviceToHost));
+        if (status) HIPTRY(hipMemcpy(status, pl->d_status, sizeof(int) * B, hipMemcpyDeviceToHost));
+        HIPTRY(hipGetLastError());
     } while (0);
     hipFree(d_dense);
     kbdm_plan_destroy(pl);

@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ ite
 // window (bdsqr_stream_lane), no LDS, so many wavefronts share a SIMD.  grid (ceil(2 m / 64), members, 2).
 __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                       cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
-                                                      int* iwork, int wait_flag) {
+                                                      int* iwork, int wait_flag, int* status, unsigned spin_limit) {
     const int item = perm[blockIdx.y];
     const KbItem it = items[item];
     const int m = it.m;
@@ -332,7 +332,12 @@ __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ 
         int avail = __builtin_amdgcn_readfirstlane(
             __hip_atomic_load(&iwork[4 * item + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (!done && avail <= b) {
-            if (++spins > (1u << 26)) return;          // generator lost: leave (status is set by k_bdsqr_sort's checks)
+            if (++spins > spin_limit) {
+                // generator lost (it never became resident: streams sharing a hardware queue, or it died): this member's
+                // Q / P stay un-replayed - flag the member, never return a silent answer
+                if (threadIdx.x == 0) atomicOr(&status[item], KB_STAT_SVD_NOCONV);
+                return;
+            }
             __builtin_amdgcn_s_sleep(32);
             continue;
         }

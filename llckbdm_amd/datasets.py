@@ -47,6 +47,14 @@ def config2(seed=0):
     return sig.reshape(1, -1), np.zeros(len(m), dtype=np.int32), m
 
 
+def north_star(seed=0, step=2):
+    """The ensemble BASELINE.json's north_star quotes its target on: N=2048, 16 peaks, sigma=1e-3,
+    m = 100..500 (step 2: 201 members; the sum of m^3 is 1.84 x that of C2)."""
+    sig = add_noise(brain_sim_signal(2048), 1e-3, seed)
+    m = np.arange(100, 501, step, dtype=np.int32)
+    return sig.reshape(1, -1), np.zeros(len(m), dtype=np.int32), m
+
+
 def config3(count=1024, m=512, seed0=0):
     """C3: pseudo-noise ensemble, fixed m, one sigma=1e-6 noise draw per member."""
     base = brain_sim_signal(2048)

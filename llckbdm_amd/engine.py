@@ -5,6 +5,7 @@ This is the host half of the batched replacement for the reference's serial loop
 """
 import os
 import threading
+from collections import OrderedDict
 
 import numpy as np
 
@@ -130,22 +131,47 @@ class Engine:
         h = _lib.c_void_p()
         _lib.check(self.lib.kbdm_ctx_create(self.device, h))
         self.ctx = h
+        # plans of recent `solve` calls, keyed on the batch geometry: a plan owns its device workspace (about 1 GB
+        # for a C2 ensemble), and callers such as `sample_kbdm` / `iterative_llc_kbdm` solve the same geometry
+        # again and again with new signals
+        self._plan_cache = OrderedDict()
+        self.plan_cache_size = int(os.environ.get("KBDM_PLAN_CACHE", "4"))
 
     def plan(self, S, N, sig_idx, m, l, p=1, q=0.0, dwell=1.0):
         return Plan(self, S, N, sig_idx, m, l, p, q, dwell)
 
+    def cached_plan(self, S, N, sig_idx, m, l, p=1, q=0.0, dwell=1.0):
+        """The plan for this batch geometry, created on first use and kept (LRU, `plan_cache_size` entries)."""
+        sig_idx = np.ascontiguousarray(sig_idx, dtype=np.int32)
+        m = np.ascontiguousarray(m, dtype=np.int32)
+        l = np.ascontiguousarray(l, dtype=np.int32)
+        key = (int(S), int(N), sig_idx.tobytes(), m.tobytes(), l.tobytes(), int(p), float(q), float(dwell))
+        plan = self._plan_cache.get(key)
+        if plan is not None and plan.handle is not None:
+            self._plan_cache.move_to_end(key)
+            return plan
+        plan = self.plan(S, N, sig_idx, m, l, p, q, dwell)
+        self._plan_cache[key] = plan
+        while len(self._plan_cache) > max(1, self.plan_cache_size):
+            _, old = self._plan_cache.popitem(last=False)
+            old.close()
+        return plan
+
+    def clear_plan_cache(self):
+        for plan in self._plan_cache.values():
+            plan.close()
+        self._plan_cache.clear()
+
     def solve(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0):
-        """signals: (S, N) complex; items (sig_idx[i], m[i], l[i]).  Returns BatchResult."""
+        """signals: (S, N) complex; items (sig_idx[i], m[i], l[i]).  Returns BatchResult.
+        The plan (device workspace) of a geometry is reused by later calls with the same geometry."""
         signals = np.ascontiguousarray(np.atleast_2d(signals), dtype=np.complex128)
         m = np.asarray(m, dtype=np.int32)
         l = m.copy() if l is None else np.asarray(l, dtype=np.int32)
-        plan = self.plan(signals.shape[0], signals.shape[1], sig_idx, m, l, p, q, dwell)
-        try:
-            plan.upload(signals)
-            plan.execute()
-            return plan.download()
-        finally:
-            plan.close()
+        plan = self.cached_plan(signals.shape[0], signals.shape[1], sig_idx, m, l, p, q, dwell)
+        plan.upload(signals)
+        plan.execute()
+        return plan.download()
 
     # ---- stage entry points (parity tests) -------------------------------------------
     def hankel(self, signals, sig_idx, m, p):
@@ -236,6 +262,7 @@ class Engine:
 
     def close(self):
         if self.ctx is not None:
+            self.clear_plan_cache()
             self.lib.kbdm_ctx_destroy(self.ctx)
             self.ctx = None
 

@@ -49,6 +49,8 @@ class ClusteringResult:
 
 
 MIN_CLUSTER_SIZE = 5        # hdbscan.HDBSCAN's default, which the reference does not change (llckbdm.py:280)
+GPU_SWEEP_MAX_K = 300       # the k-nearest-neighbour pass of `Engine.hdbscan_sweep` keeps a lane's K candidates in LDS
+                            # ((64 K + 512) doubles per workgroup): larger min_samples go to scikit-learn's HDBSCAN
 
 
 def _fit_labels(transformed_samples, min_samples, clusterer, engine):
@@ -85,9 +87,14 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None, clusterer="g
     labels_all = None
     if clusterer == "gpu" and len(transformed_line_list) >= 2:
         fits = [k for k in sweep if k <= len(transformed_line_list)]
-        if fits:
-            got, _ = eng.hdbscan_sweep(transformed_line_list, fits, MIN_CLUSTER_SIZE)
-            labels_all = dict(zip(fits, got))
+        labels_all = {}
+        on_gpu = [k for k in fits if k <= GPU_SWEEP_MAX_K]
+        if on_gpu:
+            got, _ = eng.hdbscan_sweep(transformed_line_list, on_gpu, MIN_CLUSTER_SIZE)
+            labels_all.update(zip(on_gpu, got))
+        for k in fits:                       # ensembles of more than GPU_SWEEP_MAX_K members (e.g. config 4's m_range)
+            if k > GPU_SWEEP_MAX_K:
+                labels_all[k] = _fit_labels(transformed_line_list, k, "sklearn", eng)
     for min_samples in sweep:
         logger.debug('HDBSCAN with min_samples = %d', min_samples)
         if clusterer == "gpu" and (labels_all is None or min_samples not in labels_all):
@@ -108,42 +115,42 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None, clusterer="g
 
 def iterative_llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, max_iterations=5, silhouette_threshold=0.6,
                        engine=None, clusterer="gpu"):
-    """Residual peeling driver.  Reference: llckbdm.py:144-199."""
+    """Residual peeling: fit the lines LLC-KBDM is confident about, subtract their model signal, fit the rest
+    again with a lower confidence bar.  Behaviour of the reference's llckbdm.py:144-199: the bar of round k is the
+    `np.percentile` of that round's cluster silhouettes at rank  threshold * (1 - k / (rounds - 1))  (a 0..0.6
+    PERCENT rank, as upstream), strictly-greater selection, the final RMSE is the model against itself, progress is
+    printed.  (One quirk is not kept: a round in which no cluster clears the bar ends the peeling here, where the
+    reference would crash inside `multi_fid` on an empty table.)"""
     if max_iterations < 1:
         raise ValueError("'max_iterations must be greater than zero")
     eng = engine or default_engine()
-    data = np.asarray(data)
-    curr_data_est = np.zeros_like(data)
-    line_lists = []
-    silhouettes = []
-    t_array, _ = gen_t_freq_arrays(N=len(data), dwell=dwell)
-    n_peaks = 0
-    silhouette_thresholds = np.linspace(silhouette_threshold, 0, max_iterations)
-    for i in range(max_iterations):
-        logger.info('Iteration #%d', i)
-        curr_res = data - curr_data_est
-        results = llc_kbdm(data=curr_res, dwell=dwell, m_range=m_range, p=p, l=l, q=q, engine=eng, clusterer=clusterer)
-        if len(results.line_list) == 0:
-            logger.info('No more peaks can be fitted. Stopping.')
+    observed = np.asarray(data)
+    t_axis = gen_t_freq_arrays(N=len(observed), dwell=dwell)[0]
+    model = np.zeros_like(observed)                  # signal of everything accepted so far
+    accepted = []                                    # one (lines, silhouettes) pair per productive round
+    percent_ranks = np.linspace(silhouette_threshold, 0, max_iterations)
+    for round_no, rank in enumerate(percent_ranks):
+        print(f'Iteration #{round_no}')
+        fit = llc_kbdm(data=observed - model, dwell=dwell, m_range=m_range, p=p, l=l, q=q, engine=eng,
+                       clusterer=clusterer)
+        if len(fit.line_list) == 0:
+            logging.info('No more peaks can be fitted. Stopping.')      # root logger, as upstream (llckbdm.py:168)
             break
-        filtered_index = np.nonzero(
-            (results.silhouette > np.percentile(results.silhouette, silhouette_thresholds[i])))
-        line_list = results.line_list[filtered_index]
-        if len(line_list) == 0:
-            # the reference would call multi_fid with no peaks here and fail inside numpy; nothing is left to fit
-            logger.info('No peak passed the silhouette threshold. Stopping.')
+        confident = fit.silhouette > np.percentile(fit.silhouette, rank)
+        if not confident.any():
+            logging.info('No peak passed the silhouette threshold. Stopping.')
             break
-        curr_data_est_i = multi_fid(t_array=t_array, params=line_list)
-        curr_data_est = curr_data_est + curr_data_est_i
-        line_lists.append(line_list)
-        silhouettes.append(results.silhouette[filtered_index])
-        n_peaks += len(line_list)
-        logger.info('Found %d peaks. Total: %d peaks.', len(line_list), n_peaks)
-    if not line_lists:
+        lines = fit.line_list[confident]
+        model = model + multi_fid(t_array=t_axis, params=lines)
+        accepted.append((lines, fit.silhouette[confident]))
+        print(f'Found {len(lines)} peaks. Total: {sum(len(a) for a, _ in accepted)} peaks.')
+    if not accepted:
         return IterativeLlcKbdmResult(line_list=np.array([]), line_lists=[], silhouettes=[], rmse=None)
-    line_list = np.concatenate(line_lists)
-    rmse = calculate_freq_domain_rmse(data=curr_data_est, params_est=line_list, dwell=dwell, engine=eng)
-    return IterativeLlcKbdmResult(line_list=line_list, line_lists=line_lists, silhouettes=silhouettes, rmse=rmse)
+    per_round_lines = [a for a, _ in accepted]
+    everything = np.concatenate(per_round_lines)
+    rmse = calculate_freq_domain_rmse(data=model, params_est=everything, dwell=dwell, engine=eng)
+    return IterativeLlcKbdmResult(line_list=everything, line_lists=per_round_lines,
+                                  silhouettes=[s for _, s in accepted], rmse=rmse)
 
 
 def _transform_line_lists(line_lists, dwell):
@@ -170,50 +177,51 @@ def _inverse_transform_line_lists(transformed_line_lists, dwell):
 
 
 def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, clusterer="gpu", labels=None):
-    """One density clustering of the pooled lines + per-cluster mean silhouettes + summarised line list.
-    Reference: llckbdm.py:264-321.  The silhouettes come from the GPU kernel (`Engine.silhouette_samples`);
-    like `sklearn.metrics.silhouette_samples` they are undefined for fewer than 2 or more than n-1 label
-    values - the reference would raise there, here such a clustering is reported as having no clusters."""
+    """One density clustering of the pooled lines, the mean silhouette of every cluster and the summarised line
+    list.  Same result type and field meaning as the reference's llckbdm.py:264-321; the work is organised around
+    ONE stable sort of the labels (cluster index sets are slices of it, per-cluster means are segmented sums).  The
+    silhouettes come from the GPU kernel (`Engine.silhouette_samples`); like `sklearn.metrics.silhouette_samples`
+    they are undefined for fewer than 2 or more than n-1 label values - the reference would raise there, here
+    such a clustering is reported as having no clusters."""
     if labels is None:
         labels = _fit_labels(transformed_samples, min_samples, clusterer, engine)
     labels = np.asarray(labels)
-    num_clusters = len(set(labels.tolist()) - {-1})
-    n_labels = len(set(labels.tolist()))
-    clustered = []
-    if num_clusters > 0 and 2 <= n_labels <= len(labels) - 1:
-        eng = engine or default_engine()
-        sample_silhouette_values = eng.silhouette_samples(transformed_samples, labels)
-        clustered_silhouettes = []
-        for cluster_label in range(num_clusters):
-            cluster = np.nonzero(labels == cluster_label)
-            clustered.append(cluster)
-            clustered_silhouettes.append(np.average(sample_silhouette_values[cluster]))
-        non_clustered = np.nonzero(labels == -1)
-        summarized_line_list = _summarize_clusters(samples=samples, clusters=clustered)
-        clustered_arr = np.empty(len(clustered), dtype=object)
-        for i, c in enumerate(clustered):
-            clustered_arr[i] = c
-    else:
-        num_clusters = 0
-        non_clustered = []
-        summarized_line_list = []
-        clustered_silhouettes = []
-        clustered_arr = np.array([])
-    return ClusteringResult(num_clusters=num_clusters, labels=labels, clustered=clustered_arr,
-                            non_clustered=np.array(non_clustered), summarized_line_list=summarized_line_list,
-                            clustered_silhouettes=np.array(clustered_silhouettes))
+    order = np.argsort(labels, kind="stable")                 # noise (-1) first, then cluster 0, 1, ...
+    sorted_labels = labels[order]
+    num_clusters = int(sorted_labels[-1]) + 1 if len(labels) and sorted_labels[-1] >= 0 else 0
+    distinct = num_clusters + (1 if len(labels) and sorted_labels[0] < 0 else 0)
+    if num_clusters == 0 or not (2 <= distinct <= len(labels) - 1):
+        return ClusteringResult(num_clusters=0, labels=labels, clustered=np.array([]), non_clustered=np.array([]),
+                                summarized_line_list=[], clustered_silhouettes=np.array([]))
+    starts = np.searchsorted(sorted_labels, np.arange(num_clusters + 1))       # slice k = members of cluster k
+    members = [(np.sort(order[starts[k]:starts[k + 1]]),) for k in range(num_clusters)]   # np.nonzero-style tuples
+    sil = (engine or default_engine()).silhouette_samples(transformed_samples, labels)
+    counts = np.diff(starts)
+    mean_sil = np.add.reduceat(sil[order], starts[:-1])[:num_clusters] / counts
+    clustered = np.empty(num_clusters, dtype=object)
+    for k, idx in enumerate(members):
+        clustered[k] = idx
+    return ClusteringResult(num_clusters=num_clusters, labels=labels, clustered=clustered,
+                            non_clustered=np.array((np.sort(order[:starts[0]]),)),
+                            summarized_line_list=_summarize_clusters(samples=samples, clusters=members),
+                            clustered_silhouettes=mean_sil)
 
 
 def _summarize_clusters(samples, clusters, summarizer=np.average):
-    """One line per cluster: the average of (A, F, PH) and the HARMONIC average of T2 (the cluster's T2 column is
-    inverted before and after the summary).  Reference: llckbdm.py:324-353."""
-    line_list = []
-    if summarizer is None:
-        summarizer = np.average
-    for cluster in clusters:
-        cluster_samples = samples[cluster]                 # fancy indexing: a copy, as in the reference
-        cluster_samples[:, 1] = 1 / cluster_samples[:, 1]
-        summarized_cluster = summarizer(cluster_samples, axis=0)
-        summarized_cluster[1] = 1 / summarized_cluster[1]
-        line_list.append(summarized_cluster)
-    return np.array(line_list)
+    """One line per cluster (reference llckbdm.py:324-353): `summarizer(rows, axis=0)` of the cluster's rows with the
+    T2 column replaced by the decay RATE 1/T2 - i.e. T2 is summarised harmonically - and turned back afterwards.
+    `samples` is not modified.  The default (mean) is evaluated for all clusters at once as segmented sums."""
+    samples = np.asarray(samples, dtype=np.float64)
+    index_sets = [np.asarray(c[0] if isinstance(c, tuple) else c).ravel() for c in clusters]
+    if not index_sets:
+        return np.array([])
+    rate_space = samples.copy()
+    rate_space[:, 1] = 1.0 / rate_space[:, 1]
+    if summarizer is None or summarizer is np.average or summarizer is np.mean:
+        flat = np.concatenate(index_sets)
+        sizes = np.array([len(ix) for ix in index_sets])
+        out = np.add.reduceat(rate_space[flat], np.concatenate(([0], np.cumsum(sizes)[:-1])), axis=0) / sizes[:, None]
+    else:
+        out = np.array([summarizer(rate_space[ix], axis=0) for ix in index_sets], dtype=np.float64)
+    out[:, 1] = 1.0 / out[:, 1]
+    return out

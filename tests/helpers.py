@@ -40,3 +40,16 @@ def genuine_rows(canon_ll, truth, freq_tol=0.5):
         assert cand.size, f"no line near {f} Hz"
         rows.append(cand[np.argmax(canon_ll[cand, 0])])
     return canon_ll[np.array(rows)]
+
+
+def resolved_genuine_rows(want, truth, freq_tol=0.5):
+    """Row indices (into a canonical line list) of the true peaks that the REFERENCE side resolves: for every true
+    frequency the line of largest amplitude within `freq_tol` Hz, if there is one (weak or broad peaks drop out at
+    small m, under heavy noise or with q > 0).  Canonical lists of equal length correspond row by row, so the same
+    indices address the other side."""
+    rows = []
+    for f in np.asarray(truth)[:, 2]:
+        cand = np.where(np.abs(want[:, 2] - f) < freq_tol)[0]
+        if cand.size:
+            rows.append(int(cand[np.argmax(want[cand, 0])]))
+    return np.array(sorted(set(rows)), dtype=np.int64)

@@ -52,11 +52,15 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import kbdm_oracle as O
-        from llckbdm_amd.distributed import sample_kbdm_sharded
+        from llckbdm_amd.distributed import GlooComm, sample_kbdm_sharded
         sig = O.make_noisy(O.brain_sim_signal(512), 1e-3, 0)
         m_range = [40, 64, 33, 100, 80]
-        lls, infos = sample_kbdm_sharded(sig, 5e-4, m_range, p=1, l=None, q=0, solve=_oracle_solve)
-        q.put((rank, [x.tolist() for x in lls], [i.m for i in infos]))
+        comm = GlooComm(_oracle_solve)
+        lls, infos = sample_kbdm_sharded(sig, 5e-4, m_range, p=1, l=None, q=0, comm=comm)
+        # gather to one root only: the other rank gets nothing
+        rl, ri = sample_kbdm_sharded(sig, 5e-4, m_range, p=1, l=30, q=0, comm=comm, root=-1)
+        q.put((rank, [x.tolist() for x in lls], [i.m for i in infos], [x.tolist() for x in rl],
+               [i.singular_values.tolist() for i in ri]))
     finally:
         dist.destroy_process_group()
 
@@ -80,8 +84,60 @@ def test_sharded_sampler_world2_gloo():
     sig = O.make_noisy(O.brain_sim_signal(512), 1e-3, 0)
     m_range = [40, 64, 33, 100, 80]
     ref_l, ref_i = O.sample_kbdm(sig, 5e-4, m_range, p=1, l=None, q=0, normalizer="gemm")
-    for rank, lls, ms in outs:                 # every rank holds the complete, ordered result
+    ref_l30, ref_i30 = O.sample_kbdm(sig, 5e-4, m_range, p=1, l=30, q=0, normalizer="gemm")
+    for rank, lls, ms, l30, sv30 in outs:      # every rank holds the complete, ordered result, bit for bit
         assert ms == [i.m for i in ref_i]
         assert len(lls) == len(ref_l)
         for a, b in zip(lls, ref_l):
             assert np.array_equal(np.array(a), b)
+        assert len(l30) == len(ref_l30)
+        for a, b in zip(l30, ref_l30):
+            assert np.array_equal(np.array(a).reshape(-1, 4), b)
+        for a, info in zip(sv30, ref_i30):
+            assert np.array_equal(np.array(a), info.singular_values)
+
+
+def test_packed_block_layout_roundtrip():
+    """Host packing == the layout include/kbdm_hip.h documents for kbdm_plan_gather; sizes match kbdm_packed_bytes."""
+    from llckbdm_amd import _lib
+    from llckbdm_amd.distributed import pack_block, packed_bytes, unpack_block
+    rng = np.random.default_rng(0)
+    for nl, nsv, nb in ((0, 0, 0), (7, 5, 2), (1000, 333, 17)):
+        lines, sv = rng.standard_normal((nl, 4)), rng.standard_normal(nsv)
+        status, keep = rng.integers(0, 8, nb).astype(np.int32), rng.integers(0, 2, nl).astype(np.uint8)
+        blk = pack_block(lines, sv, status, keep)
+        assert blk.size == packed_bytes(nl, nsv, nb) and blk.size % 16 == 0
+        assert blk.size == _lib.load().kbdm_packed_bytes(nl, nsv, nb)
+        a, b, c, d = unpack_block(blk, nl, nsv, nb)
+        assert np.array_equal(a, lines) and np.array_equal(b, sv) and np.array_equal(c, status)
+        assert np.array_equal(d, keep.astype(bool))
+
+
+@pytest.mark.gpu
+def test_rccl_gather_one_rank_rehearsal_matches_download():
+    """The C-ABI gather (pack on the device + the grouped transfer, here with one rank) returns exactly what
+    kbdm_plan_download returns, and sample_kbdm_sharded over RcclComm equals sample_kbdm bit for bit."""
+    from llckbdm_amd import datasets
+    from llckbdm_amd.distributed import RcclComm, packed_bytes, sample_kbdm_sharded, unpack_block
+    from llckbdm_amd.engine import Engine
+    from llckbdm_amd.sampling import sample_kbdm
+    eng = Engine(0)
+    sig = datasets.add_noise(datasets.brain_sim_signal(1024), 1e-3, 3)
+    ms = np.array([64, 100, 37, 150], dtype=np.int32)
+    plan = eng.plan(1, 1024, np.zeros(4, np.int32), ms, ms, p=1, q=0.0, dwell=5e-4)
+    plan.upload(sig.reshape(1, -1))
+    plan.execute()
+    ref = plan.download()
+    comm = RcclComm(eng, 1, 0, lambda uid: uid, force=True)      # a real one-rank RCCL communicator
+    sizes = np.array([packed_bytes(plan.total_lines, plan.total_sv, plan.B)], dtype=np.int64)
+    buf = comm.gather_plan(plan, sizes)
+    ll, sv, st, kp = unpack_block(buf, plan.total_lines, plan.total_sv, plan.B)
+    assert np.array_equal(ll, ref.lines) and np.array_equal(sv, ref.sv)
+    assert np.array_equal(st, ref.status) and np.array_equal(kp, ref.keep.astype(bool))
+    a_l, a_i = sample_kbdm_sharded(sig, 5e-4, ms.tolist(), p=1, l=None, q=0, comm=comm)
+    b_l, b_i = sample_kbdm(sig, 5e-4, ms.tolist(), p=1, l=None, q=0, engine=eng)
+    assert len(a_l) == len(b_l)
+    for x, y in zip(a_l, b_l):
+        assert np.array_equal(x, y)
+    for x, y in zip(a_i, b_i):
+        assert np.array_equal(x.singular_values, y.singular_values)

@@ -18,7 +18,7 @@ def eng():
     e.close()
 
 
-def _check(eng, sigs, sig_idx, ms, nsample=24):
+def _check(eng, sigs, sig_idx, ms, nsample=24, oracle_members=(), truth=None):
     from llckbdm_amd import datasets
     res = eng.solve(sigs, sig_idx, ms, None, p=1, q=0.0, dwell=datasets.DWELL)
     assert not (res.status & 3).any()                 # SVD / eigenvalue iteration converged everywhere
@@ -40,6 +40,23 @@ def _check(eng, sigs, sig_idx, ms, nsample=24):
         solo = eng.solve(sigs[sig_idx[i]].reshape(1, -1), [0], [int(ms[i])], None, p=1, q=0.0, dwell=datasets.DWELL)
         assert np.array_equal(solo.line_list(0), res.line_list(i))
         assert np.array_equal(solo.singular_values(0), res.singular_values(i))
+    # three members of the full-size batch against the oracle, eig stage and epilogue included: kept-line count,
+    # singular values, every kept line with A > 1e-4 to 1e-7 and the lines on the true frequencies to 1e-8
+    from oracle import kbdm_oracle as O          # checker only
+    from tests.helpers import assert_lines_close, canonical, keep_mask, resolved_genuine_rows
+    for i in oracle_members:
+        m = int(ms[i])
+        want, info = O.kbdm(sigs[sig_idx[i]], datasets.DWELL, m=m, normalizer="gemm")
+        got = res.line_list(i)
+        assert np.abs(res.singular_values(i) - info.singular_values).max() < 1e-14 * info.singular_values[0] * m
+        k, w = canonical(got[keep_mask(got)]), canonical(O.filter_samples(want))
+        assert len(k) == len(w), f"member {i} (m={m}): kept {len(k)} vs {len(w)}"
+        strong = w[:, 0] > 1e-4
+        assert_lines_close(k[strong], w[strong], rel=1e-7, phase_abs=1e-7, what=f"member {i} m={m} strong")
+        if truth is not None:
+            rows = resolved_genuine_rows(w, truth)
+            assert len(rows) >= 14
+            assert_lines_close(k[rows], w[rows], rel=1e-8, phase_abs=1e-8, what=f"member {i} m={m} genuine")
     return res
 
 
@@ -47,18 +64,19 @@ def test_config3_full_1024_draws_m512(eng):
     from llckbdm_amd import datasets
     sigs, sig_idx, ms = datasets.config3()
     assert len(ms) == 1024 and set(ms) == {512}
-    _check(eng, sigs, sig_idx, ms)
+    _check(eng, sigs, sig_idx, ms, oracle_members=(0, 511, 1023), truth=datasets.BRAIN_SIM_PARAMS)
 
 
 def test_config5_full_64_voxels_x_256_members(eng):
     from llckbdm_amd import datasets
     sigs, sig_idx, ms = datasets.config5()
     assert len(ms) == 16384 and sigs.shape == (64, 2048)
-    _check(eng, sigs, sig_idx, ms)
+    _check(eng, sigs, sig_idx, ms, oracle_members=(0, 8000, 16383))       # m = 128, 192, 383 of three voxels
 
 
 def test_config4_full_m200_to_1200_N4096(eng):
     from llckbdm_amd import datasets
     sigs, sig_idx, ms = datasets.config4()
     assert len(ms) == 1001 and sigs.shape == (1, 4096) and ms[-1] == 1200
-    _check(eng, sigs, sig_idx, ms, nsample=12)
+    # m = 200, 700 and 1200 (the oracle needs ~10 s for the largest)
+    _check(eng, sigs, sig_idx, ms, nsample=12, oracle_members=(0, 500, 1000))

@@ -1,0 +1,211 @@
+"""GPU parity, round 2 (through the C ABI): the holes the round-1 review listed.
+  * a replay that loses its generator flags the member (never a silent answer)           [kbdm.py:166 replacement]
+  * cluster MEMBERSHIP: the same clusterer on GPU-produced and on oracle-produced lines gives identical labels for
+    every min_samples of the reference's sweep (north_star: "bit-exact on cluster membership indices";
+    SURVEY.md 8c's definition; reference llckbdm.py:104, 280-305)
+  * reference-generated goldens: a WELL-POSED Tikhonov case (kbdm.py:179-184) and a config-4 member (N = 4096, m = 611)
+  * three ensembles in flight (the bench default) leave every bit unchanged
+  * a random ragged sweep against the oracle with asserted bounds, genuine and spurious lines separated."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import kbdm_oracle as O          # checker only
+from tests.helpers import assert_lines_close, canonical, keep_mask, resolved_genuine_rows
+
+pytestmark = pytest.mark.gpu
+DWELL = 5e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from llckbdm_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def golden_r2():
+    with np.load(os.path.join(ROOT, "tests", "golden", "kbdm_golden_r2.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_lost_generator_is_flagged_not_silent(eng):
+    """k_bdsqr_stream follows k_bdsqr_gen through in-kernel flags.  With the poll budget cut to one look the replay
+    of the large members gives up before their generators have published anything: those members must carry the
+    SVD status bit, and every member WITHOUT the bit must be bit-identical to the normal run."""
+    from llckbdm_amd import datasets
+    sigs, sig_idx, ms = datasets.config2(seed=3)
+    ms = ms[::6]
+    good = eng.solve(sigs, sig_idx[::6], ms, ms, p=1, q=0.0, dwell=DWELL)
+    assert not good.status.any()
+    os.environ["KBDM_BDSQR_SPIN_LIMIT"] = "1"
+    try:
+        bad = eng.solve(sigs, sig_idx[::6], ms, ms, p=1, q=0.0, dwell=DWELL)
+    finally:
+        del os.environ["KBDM_BDSQR_SPIN_LIMIT"]
+    flagged = (bad.status & 1) != 0
+    assert flagged.any(), "the forced give-up was not reported"
+    for i in np.nonzero(~flagged)[0]:
+        assert np.array_equal(bad.line_list(i), good.line_list(i))
+        assert np.array_equal(bad.singular_values(i), good.singular_values(i))
+    again = eng.solve(sigs, sig_idx[::6], ms, ms, p=1, q=0.0, dwell=DWELL)      # and the context is healthy afterwards
+    assert not again.status.any() and np.array_equal(again.lines, good.lines)
+
+
+def _pooled_features(line_lists, dwell):
+    """Pool member line lists in a canonical row order (members in m order, rows by frequency then 1/T2), filter, and
+    map to the clustering space of llckbdm.py:202-230."""
+    from llckbdm_amd.llckbdm import _transform_line_lists
+    pooled = np.concatenate([canonical(x) for x in line_lists])
+    return pooled, _transform_line_lists(pooled, dwell)
+
+
+@pytest.mark.parametrize("clusterer", ["gpu", "sklearn"])
+def test_cluster_membership_identical_for_gpu_and_oracle_lines(eng, clusterer):
+    from llckbdm_amd.llckbdm import MIN_CLUSTER_SIZE
+    from llckbdm_amd.sampling import sample_kbdm
+    sig = O.make_noisy(O.brain_sim_signal(1024), 1e-3, 11)
+    m_range = list(range(80, 128, 4))                                   # 12 members
+    g_l, _ = sample_kbdm(sig, DWELL, m_range, p=1, l=None, q=0, engine=eng)
+    o_l, _ = O.sample_kbdm(sig, DWELL, m_range, p=1, l=None, q=0, normalizer="gemm")
+    assert [len(a) for a in g_l] == [len(b) for b in o_l]               # same kept lines, member by member
+    g_pool, g_x = _pooled_features(g_l, DWELL)
+    o_pool, o_x = _pooled_features(o_l, DWELL)
+    assert g_x.shape == o_x.shape and np.abs(g_x - o_x).max() < 1e-7
+    sweep = list(range(1, len(m_range)))                                # llckbdm.py:104
+    if clusterer == "gpu":
+        g_lab, _ = eng.hdbscan_sweep(g_x, sweep, MIN_CLUSTER_SIZE)
+        o_lab, _ = eng.hdbscan_sweep(o_x, sweep, MIN_CLUSTER_SIZE)
+    else:
+        from sklearn.cluster import HDBSCAN
+        fit = lambda X, k: HDBSCAN(min_samples=k, min_cluster_size=MIN_CLUSTER_SIZE, copy=True).fit(X).labels_
+        g_lab = np.array([fit(g_x, k) for k in sweep])
+        o_lab = np.array([fit(o_x, k) for k in sweep])
+    for k, a, b in zip(sweep, g_lab, o_lab):
+        assert np.array_equal(a, b), f"min_samples={k}: {int((a != b).sum())} membership indices differ"
+    assert max(len(set(r.tolist()) - {-1}) for r in g_lab) >= 10       # the sweep does find the peaks' clusters
+
+
+def _solve_case(eng, g, name):
+    from llckbdm_amd.kbdm import kbdm
+    m, l, p = (int(x) for x in g[f"{name}__meta"])
+    q = float(g[f"{name}__q"][0])
+    sig = g[str(g[f"{name}__sig"])]
+    ll, info = kbdm(sig, DWELL, m=m, p=p, l=(None if l == m else l), q=q, engine=eng)
+    return ll, info, m
+
+
+def test_well_posed_tikhonov_golden(eng, golden_r2, golden):
+    """sigma = 1e-3, m = 256, q = 1e-3 (reference kbdm.py:179-184): every kept line - genuine or noise-fitted - to 1e-7,
+    the lines on the 16 true frequencies to 1e-8, kept counts and singular values as the reference's."""
+    ll, info, m = _solve_case(eng, golden_r2, "n3m256q")
+    ref_sv = golden_r2["n3m256q__sv"]
+    assert np.abs(info.singular_values - ref_sv).max() < 1e-14 * ref_sv[0] * m
+    kept, want = canonical(ll[keep_mask(ll)]), golden_r2["n3m256q__kept"]
+    assert len(kept) == len(want)
+    assert_lines_close(kept, want, rel=1e-7, phase_abs=1e-7, what="n3m256q all")
+    # the lines on the true frequencies (rows correspond one to one in canonical order); with q > 0 the broadest peak
+    # (75 Hz, T2 = 2.7 ms) is not resolved by the reference either, so only the peaks the REFERENCE resolves count
+    rows = resolved_genuine_rows(want, golden["params_sorted"])
+    assert len(rows) >= 14
+    assert_lines_close(kept[rows], want[rows], rel=1e-8, phase_abs=1e-8, what="n3m256q genuine")
+
+
+def test_config4_member_golden(eng, golden_r2):
+    """N = 4096, 32 peaks, m = 611 (BASELINE.json config 4): the 32 genuine lines to 1e-8, every kept line to 1e-7."""
+    ll, info, m = _solve_case(eng, golden_r2, "c4m611")
+    ref_sv = golden_r2["c4m611__sv"]
+    assert np.abs(info.singular_values - ref_sv).max() < 1e-14 * ref_sv[0] * m
+    kept, want = canonical(ll[keep_mask(ll)]), golden_r2["c4m611__kept"]
+    assert len(kept) == len(want)
+    rows = resolved_genuine_rows(want, golden_r2["params32"])
+    assert len(rows) >= 28                      # two pairs of the 32 peaks overlap within their line widths
+    assert_lines_close(kept[rows], want[rows], rel=1e-8, phase_abs=1e-8, what="c4m611 genuine")
+    assert_lines_close(kept, want, rel=1e-7, phase_abs=1e-7, what="c4m611 all")
+
+
+def test_three_ensembles_in_flight_give_the_same_bits():
+    """bench.py's default keeps THREE ensembles in flight (three Engines, one plan each, staggered by wait_stage):
+    contention between them must not change a bit of any result."""
+    from llckbdm_amd import datasets
+    from llckbdm_amd.engine import Engine
+    engs = [Engine(0) for _ in range(3)]
+    try:
+        plans, ref = [], []
+        for k, e in enumerate(engs):
+            sigs, sig_idx, ms = datasets.config2(seed=60 + k)
+            ms = ms[::5]                                   # 31 members, m = 100..400
+            p = e.plan(sigs.shape[0], sigs.shape[1], sig_idx[::5], ms, ms, p=1, q=0.0, dwell=datasets.DWELL)
+            p.upload(sigs)
+            p.execute(sync=True)                           # alone
+            r = p.download()
+            ref.append((r.lines.copy(), r.sv.copy(), r.status.copy()))
+            plans.append(p)
+        for rounds in range(2):
+            plans[0].execute(sync=False)
+            plans[0].wait_stage("k_bdsqr_sort")
+            plans[1].execute(sync=False)
+            plans[1].wait_stage("k_bdsqr_sort")
+            plans[2].execute(sync=False)
+            plans[0].sync()
+            plans[0].execute(sync=False)                   # overlaps the tails of plans 1 and 2
+            for p in plans:
+                p.sync()
+            for p, (lines, sv, status) in zip(plans, ref):
+                r = p.download()
+                assert np.array_equal(r.status, status)
+                assert np.array_equal(r.lines, lines)
+                assert np.array_equal(r.sv, sv)
+    finally:
+        for e in engs:
+            e.close()
+
+
+@pytest.mark.parametrize("p,q,bound_strong", [(1, 0.0, 2e-8), (2, 0.0, 2e-8), (1, 1e-3, 5e-8)])
+def test_random_ragged_sweep_against_oracle(eng, p, q, bound_strong):
+    """tools/stress_parity.py as a test: ragged random members (m = 20..330, l <= m, N in {1024, 2048},
+    sigma in {1e-4, 1e-3, 1e-2}) against the oracle on the host.  Asserted: kept-line counts equal for every
+    member; singular values to 1e-15 m s0; the lines ON the 16 true frequencies to 1e-8; every kept line with
+    amplitude > 1e-4 (mostly noise-fitted, i.e. spurious) within `bound_strong` - LAPACK's own two SVD drivers differ
+    by 4e-8 on such lines."""
+    rng = np.random.default_rng(5 + p)
+    base = {1024: O.brain_sim_signal(1024), 2048: O.brain_sim_signal(2048)}
+    truth = O.brain_sim_params_sorted()
+    B = 60
+    sigs, Ns, ms, ls = [], [], [], []
+    for b in range(B):
+        N = int(rng.choice([1024, 2048]))
+        sigma = float(rng.choice([1e-3, 1e-2, 1e-4]))
+        m = int(rng.integers(20, 330))
+        l = m if rng.random() < 0.7 else int(rng.integers(max(4, m // 4), m + 1))
+        sigs.append(O.make_noisy(base[N], sigma, 9000 + 100 * p + b)); Ns.append(N); ms.append(m); ls.append(l)
+    worst_strong = worst_genuine = 0.0
+    for N in (1024, 2048):
+        idx = [i for i in range(B) if Ns[i] == N]
+        S = np.stack([sigs[i] for i in idx])
+        r = eng.solve(S, list(range(len(idx))), [ms[i] for i in idx], [ls[i] for i in idx], p=p, q=q, dwell=DWELL)
+        assert not (r.status & 3).any()
+        for j, i in enumerate(idx):
+            want, info = O.kbdm(sigs[i], DWELL, m=ms[i], l=ls[i], p=p, q=q, normalizer="gemm")
+            got = r.line_list(j)
+            assert np.abs(r.singular_values(j) - info.singular_values).max() < 1e-15 * info.singular_values[0] * ms[i]
+            k, w = canonical(got[keep_mask(got)]), canonical(O.filter_samples(want))
+            assert len(k) == len(w), f"member {i} (m={ms[i]}, l={ls[i]}): kept {len(k)} vs {len(w)}"
+            if len(k) == 0:
+                continue
+            rel = np.abs(k[:, :3] - w[:, :3]) / np.maximum(np.abs(w[:, :3]), 1e-300)
+            strong = w[:, 0] > 1e-4
+            if strong.any():
+                worst_strong = max(worst_strong, float(rel[strong].max()))
+            if ls[i] == ms[i] and ms[i] >= 64 and q == 0:
+                # well-posed members: the lines on the true frequencies (largest amplitude within 0.5 Hz)
+                rows = resolved_genuine_rows(w, truth)
+                if len(rows):
+                    relg = np.abs(k[rows, :3] - w[rows, :3]) / np.abs(w[rows, :3])
+                    worst_genuine = max(worst_genuine, float(relg.max()))
+    assert worst_genuine <= 1e-8, f"genuine peaks: {worst_genuine:.2e}"
+    assert worst_strong <= bound_strong, f"lines with A > 1e-4: {worst_strong:.2e}"

@@ -89,3 +89,24 @@ def test_sampler_matches_reference(golden):
 def test_filter_empty():
     e = np.array([])
     assert np.array_equal(O.filter_samples(e), e)
+
+
+@pytest.mark.parametrize("name", ["n3m256q", "c4m611"])
+def test_kbdm_matches_reference_round2_goldens(name):
+    """Round-2 vectors (tests/golden/make_golden_r2.py, made by the reference itself): a well-posed Tikhonov case
+    (kbdm.py:179-184) and a config-4 member (N = 4096, 32 peaks, m = 611)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with np.load(os.path.join(root, "tests", "golden", "kbdm_golden_r2.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    sig, m, l, p, q = _case(g, name)
+    ll, info = O.kbdm(sig, 5e-4, m=m, p=p, l=(None if l == m else l), q=q)
+    sv = g[f"{name}__sv"]
+    assert np.max(np.abs(info.singular_values - sv)) < 1e-13 * sv[0]
+    kept, want = canonical(O.filter_samples(ll)), g[f"{name}__kept"]
+    assert len(kept) == len(want)
+    assert_lines_close(kept, want, rel=1e-8, phase_abs=1e-8, what=name)
+    if name == "c4m611":
+        # the signal the product's datasets module builds for config 4 is the one the reference's sig_gen gave
+        from llckbdm_amd import datasets
+        assert np.allclose(datasets.config4()[0][0], g["sig4096_c4"], rtol=0, atol=1e-13)

@@ -1,5 +1,5 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llckbdm_amd import datasets
 from llckbdm_amd.engine import Engine
 eng=Engine(0)
