@@ -106,6 +106,7 @@ struct kbdm_ctx {
     int hqr_wgs = -1;     // workgroups of the solo k_hqr launch (members are taken from a queue, largest first):
                           // -1 = as many as the launch's work needs to last no longer than its largest member,
                           // 0 = one workgroup per member, N = fixed
+    int gen_wy = 1;       // explicit Q / P / Qh of large members by blocked compact-WY accumulation on MFMA (0: k_gen for all)
     int blocked = 1;      // blocked (panel + MFMA update) reductions; 0: unblocked kernels only (debugging)
     int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
     int hqr_v = 2;        // QR iteration: 2 = kb_hqr2.hpp (double-shift bulges, systolic strips), 1 = round-1 kernels
@@ -330,18 +331,45 @@ struct StageTimer {
 
 int smem_fac(int n, int nt) { return KB_RED_BYTES + bidiag_scratch_bytes(n, nt / 64, 64); }
 
-// k_gen with the smallest register-chunk count that covers the largest item of the launch
+// Explicit unitary factors of a chunk: members with n >= KB_WY_MIN by blocked compact-WY accumulation on FP64 MFMA
+// (three launches per block of NB reflectors, last block first), the smaller ones by the per-column kernel k_gen
+// (smallest register-chunk count that covers the largest of them).
 int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream_t gst) {
     kbdm_ctx* ctx = pl->ctx;
     const int* perm = pl->d_perm + ch.first;
-    dim3 grid(ctx->split_gen, ch.count, nmat), block(256);
-    const int chunks = (nmax + 63) / 64;
-    if (chunks <= 2) hipLaunchKernelGGL(k_gen<2>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 4) hipLaunchKernelGGL(k_gen<4>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 8) hipLaunchKernelGGL(k_gen<8>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 16) hipLaunchKernelGGL(k_gen<16>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else if (chunks <= 32) hipLaunchKernelGGL(k_gen<32>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-    else return fail(KBDM_E_NOMEM, "m larger than 2048 is not supported by k_gen");
+    const int wy = ctx->gen_wy && nmax >= KB_WY_MIN;
+    if (wy) {
+        hipLaunchKernelGGL(k_wy_init, dim3(64, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
+        const int nblk = (nmax + KB_NB - 1) / KB_NB;
+        for (int s = 0; s < nblk; ++s) {
+            // the block handled at step s of the LARGEST member starts at kb = (nblk - 1 - s) NB: its trailing size bounds the grids
+            const int span = std::min(nmax, nmax - (nblk - 1 - s) * KB_NB + 2 * KB_NB);    // (+ slack: a smaller member's block
+                                                                                        // grid may be a few rows taller)
+            const int tiles = (span + 63) / 64;
+            hipLaunchKernelGGL(k_wy_gram, dim3((span + KB_NB + 63) / 64, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm,
+                               pl->d_arena, pl->d_varena, mode, s);
+            hipLaunchKernelGGL(k_wy_t, dim3(ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s);
+            hipLaunchKernelGGL(k_wy_update, dim3(tiles, tiles, ch.count * nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena,
+                               pl->d_varena, mode, s, nmat);
+        }
+    }
+    // the per-column kernel for the members below KB_WY_MIN (all of them when the blocked path is off)
+    int nsmall = 0;
+    for (int i = 0; i < ch.count; ++i) {
+        const KbItem& it = pl->items[pl->perm[ch.first + i]];
+        const int n = mode == 0 ? it.m : it.l;
+        if (!wy || n < KB_WY_MIN) nsmall = std::max(nsmall, n);
+    }
+    if (nsmall > 0) {
+        dim3 grid(ctx->split_gen, ch.count, nmat), block(256);
+        const int chunks = (nsmall + 63) / 64;
+        if (chunks <= 2) hipLaunchKernelGGL(k_gen<2>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, wy);
+        else if (chunks <= 4) hipLaunchKernelGGL(k_gen<4>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, wy);
+        else if (chunks <= 8) hipLaunchKernelGGL(k_gen<8>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, wy);
+        else if (chunks <= 16) hipLaunchKernelGGL(k_gen<16>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, wy);
+        else if (chunks <= 32) hipLaunchKernelGGL(k_gen<32>, grid, block, 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, wy);
+        else return fail(KBDM_E_NOMEM, "m larger than 2048 is not supported by k_gen");
+    }
     return KBDM_OK;
 }
 
@@ -649,6 +677,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->win_hqr = env_int("KBDM_WIN_HQR", c->win_hqr);
     c->hqr_v = env_int("KBDM_HQR_V", c->hqr_v);
     c->blocked = env_int("KBDM_BLOCKED", c->blocked);
+    c->gen_wy = env_int("KBDM_GEN_WY", c->gen_wy);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
     c->win_hqr2 = std::min(64, std::max(3 * c->nb_hqr2 + 8, env_int("KBDM_WIN_HQR2", c->win_hqr2)));

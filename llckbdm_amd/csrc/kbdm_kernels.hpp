@@ -111,11 +111,14 @@ __global__ void __launch_bounds__(1024) k_bidiag_panel(const KbItem* __restrict_
 //   B: lane l -> B[l >> 4][l & 15],  C/D: col = l & 15, row = (l >> 4) + 4 * reg.
 //   Aop(r, k), Bop(c, k): accessors with r, c relative to the tile origin (they return 0 outside the matrix).
 typedef double kb_d4 __attribute__((ext_vector_type(4)));
+constexpr int KB_WY_MIN = 192;    // members at least this large get their unitary factors from the blocked (k_wy_*) path
 constexpr int KB_TU_KC = 8;       // k per staged chunk
 constexpr int KB_TU_PITCH = 80;   // doubles per k row in LDS
 
-template <class FA, class FB, class FC>
-__device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
+// `nch` = number of 8-deep k chunks (a runtime value: the blocked reductions use 2 NB / 8, the compact-WY generation of
+// the unitary factors uses the panel height / 8 and NB / 8); STORE = false: C -= product, true: C = product.
+template <bool STORE, class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_tile_k(FA Aop, FB Bop, FC Cptr, int NCH) {
     __shared__ double s_op[2][2][2][KB_TU_KC][KB_TU_PITCH];   // [buffer][A|B][re|im][k][row]
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
@@ -127,7 +130,6 @@ __device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
-    constexpr int NCH = 2 * KB_NB / KB_TU_KC;
     cd ga[2], gb[2];
     ga[0] = Aop(srow, sk); ga[1] = Aop(srow, sk + 4);
     gb[0] = Bop(srow, sk); gb[1] = Bop(srow, sk + 4);
@@ -183,12 +185,20 @@ __device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
             for (int g = 0; g < 4; ++g) {
                 cd* pc = Cptr(wr + rb * 16 + li, wc + cb * 16 + lk + 4 * g);
                 if (pc) {
-                    cd v = *pc;
-                    v.x -= acc_re[cb][rb][g];
-                    v.y -= acc_im[cb][rb][g];
-                    *pc = v;
+                    if (STORE) {
+                        *pc = mk(acc_re[cb][rb][g], acc_im[cb][rb][g]);
+                    } else {
+                        cd v = *pc;
+                        v.x -= acc_re[cb][rb][g];
+                        v.y -= acc_im[cb][rb][g];
+                        *pc = v;
+                    }
                 }
             }
+}
+template <class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
+    mfma_tile_k<false>(Aop, Bop, Cptr, 2 * KB_NB / KB_TU_KC);
 }
 
 // Trailing update of one panel:  C[r, c] -= sum_k Aop[r, k] conj(Bop[c, k]),  r, c in [NB, n),
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(1024) k_svd_fac(const KbItem* __restrict__ ite
 //   mode 1: Qh (from the Hessenberg vectors in P, tauh) into Q
 template <int MAXC>
 __global__ void __launch_bounds__(256) k_gen(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                              cd* arena, double* varena, int mode) {
+                                              cd* arena, double* varena, int mode, int wy) {
     const KbItem it = items[perm[blockIdx.y]];
     const DevCtx ctx = make_ctx(0);
     double* dv = varena + it.voff;
@@ -269,11 +279,161 @@ __global__ void __launch_bounds__(256) k_gen(const KbItem* __restrict__ items, c
         Out = arena + it.off[KB_BUF_Q];
     }
     if (n > MAXC * 64) return;                       // host picks MAXC from the largest item
+    if (wy && n >= KB_WY_MIN) return;                // large members: blocked accumulation (k_wy_*)
     const int cpw = (n + gridDim.x - 1) / gridDim.x;
     const int c0 = blockIdx.x * cpw;
     const int c1 = (c0 + cpw < n) ? c0 + cpw : n;
     if (c0 >= n) return;
     gen_unitary_cols<DevCtx, MAXC>(ctx, n, nref, shift, V, n, tau, Out, n, c0, c1);
+}
+
+// ------------------------------------------------------------------------------------
+// Explicit unitary factors by BLOCKED backward accumulation (the zungqr / zungbr organisation) on FP64 MFMA, for
+// members with n >= KB_WY_MIN (smaller ones keep the per-column kernel k_gen).  Q = H_0 H_1 ... H_{nref-1} is built
+// from the last block of NB reflectors to the first: with the block reflector  H_kb .. H_kb+NB-1 = I - V T V^H
+// (compact WY, T upper triangular NB x NB),  Out[p0:, p0:] <- (I - V T V^H) Out[p0:, p0:],  p0 = kb + shift, in three
+// launches per block for ALL members and both matrices:
+//   k_wy_gram   Zt = (V^H C)^T and Gt = (V^H V)^T as ONE tall product against V (MFMA tiles, k = panel height): every
+//               reflector panel is read once per 64 columns instead of once per column;
+//   k_wy_t      T from Gt and tau (zlarft), then Yc = conj(T Z)^T (NB x NB per column: vector code, one workgroup);
+//   k_wy_update C -= V Y as a rank-NB MFMA update.
+// The result is the same product of reflectors as k_gen's (rounding differs); flops 32/3 n^3 (Q, P) + 16/3 l^3 (Qh).
+struct WyGeom {
+    int n, nref, shift;
+    const cd* V;          // reflector k: column k, rows > k + shift (1 at row k + shift, 0 above)
+    const cd* tau;
+    cd* Out;              // n x n
+    cd* ws;               // workspace of this matrix: Zt (n x NB), Yc (n x NB), Gt (NB x NB), T (NB x NB)
+};
+__device__ __forceinline__ bool wy_geom(const KbItem& it, cd* arena, double* varena, int mode, int z, WyGeom& g) {
+    double* dv = varena + it.voff;
+    cd* wsbase;
+    if (mode == 0) {
+        g.n = it.m;
+        if (z == 0) { g.nref = g.n; g.shift = 0; g.V = arena + it.off[KB_BUF_A]; g.tau = reinterpret_cast<const cd*>(dv + KB_V_TAUQ * it.vstride); g.Out = arena + it.off[KB_BUF_Q]; }
+        else { g.nref = g.n - 1; g.shift = 1; g.V = arena + it.off[KB_BUF_R]; g.tau = reinterpret_cast<const cd*>(dv + KB_V_TAUP * it.vstride); g.Out = arena + it.off[KB_BUF_P]; }
+        wsbase = arena + it.off[KB_BUF_H];            // free until the Hessenberg reduction
+    } else {
+        g.n = it.l; g.nref = g.n - 2; g.shift = 1;
+        g.V = arena + it.off[KB_BUF_P]; g.tau = reinterpret_cast<const cd*>(dv + KB_V_TAUQ * it.vstride); g.Out = arena + it.off[KB_BUF_Q];
+        wsbase = arena + it.off[KB_BUF_A];            // L is dead after k_gemm<2>, B is written by k_gemm<4>
+    }
+    g.ws = wsbase + (size_t)z * (2 * KB_NB * (size_t)g.n + 2 * KB_NB * KB_NB);
+    return g.n >= KB_WY_MIN;
+}
+__device__ __forceinline__ cd wy_v(const WyGeom& g, int r, int k) {          // element (r, k) of the reflector matrix
+    if (k >= g.nref || r >= g.n) return czero();
+    const int p = k + g.shift;
+    return r > p ? g.V[r + (size_t)k * g.n] : (r == p ? mk(1.0, 0.0) : czero());
+}
+// block handled at step s (s = 0: the last block); false if this member has fewer blocks
+__device__ __forceinline__ bool wy_block(const WyGeom& g, int step, int& kb, int& p0) {
+    const int nblk = (g.nref + KB_NB - 1) / KB_NB;
+    if (step >= nblk) return false;
+    kb = (nblk - 1 - step) * KB_NB;
+    p0 = kb + g.shift;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_wy_init(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
+                                                  double* varena, int mode) {
+    const KbItem it = items[perm[blockIdx.y]];
+    WyGeom g;
+    if (!wy_geom(it, arena, varena, mode, blockIdx.z, g)) return;
+    const size_t tot = (size_t)g.n * g.n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e % g.n), c = (int)(e / g.n);
+        g.Out[e] = (r == c) ? mk(1.0, 0.0) : czero();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wy_gram(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
+                                                  double* varena, int mode, int step) {
+    const KbItem it = items[perm[blockIdx.y]];
+    WyGeom g;
+    if (!wy_geom(it, arena, varena, mode, blockIdx.z, g)) return;
+    int kb, p0;
+    if (!wy_block(g, step, kb, p0)) return;
+    const int nrows = g.n - p0, ncols = g.n - p0;
+    const int c0 = blockIdx.x * 64;
+    if (c0 >= ncols + KB_NB) return;
+    cd* Zt = g.ws;
+    cd* Gt = g.ws + 2 * KB_NB * (size_t)g.n;
+    mfma_tile_k<true>(
+        [&](int i, int kk) -> cd {                 // rows of the product: columns of C, then the NB columns of V itself
+            const int c = c0 + i;
+            if (kk >= nrows) return czero();
+            if (c < ncols) return g.Out[(p0 + kk) + (size_t)(p0 + c) * g.n];
+            return (c < ncols + KB_NB) ? wy_v(g, p0 + kk, kb + (c - ncols)) : czero();
+        },
+        [&](int j, int kk) -> cd { return (j < KB_NB && kk < nrows) ? wy_v(g, p0 + kk, kb + j) : czero(); },
+        [&](int i, int j) -> cd* {
+            const int c = c0 + i;
+            if (j >= KB_NB) return nullptr;
+            if (c < ncols) return &Zt[c + (size_t)j * g.n];
+            return (c < ncols + KB_NB) ? &Gt[(c - ncols) + j * KB_NB] : nullptr;
+        },
+        (nrows + KB_TU_KC - 1) / KB_TU_KC);
+}
+
+__global__ void __launch_bounds__(256) k_wy_t(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
+                                               double* varena, int mode, int step) {
+    const KbItem it = items[perm[blockIdx.x]];
+    WyGeom g;
+    if (!wy_geom(it, arena, varena, mode, blockIdx.y, g)) return;
+    int kb, p0;
+    if (!wy_block(g, step, kb, p0)) return;
+    const int ncols = g.n - p0;
+    const cd* Zt = g.ws;
+    cd* Yc = g.ws + KB_NB * (size_t)g.n;
+    const cd* Gt = g.ws + 2 * KB_NB * (size_t)g.n;
+    __shared__ cd T[KB_NB][KB_NB + 1];
+    __shared__ cd col[KB_NB];
+    const int t = threadIdx.x;
+    for (int e = t; e < KB_NB * (KB_NB + 1); e += blockDim.x) (&T[0][0])[e] = czero();
+    __syncthreads();
+    // zlarft, forward / columnwise: T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i;  G(l, i) = Gt[i + l NB]
+    for (int i = 0; i < KB_NB; ++i) {
+        const cd ti = (kb + i < g.nref) ? g.tau[kb + i] : czero();
+        if (t < i) col[t] = -(ti * Gt[i + t * KB_NB]);
+        __syncthreads();
+        if (t < i) {
+            cd acc = czero();
+            for (int l = t; l < i; ++l) cfma(acc, T[t][l], col[l]);
+            T[t][i] = acc;
+        }
+        if (t == i) T[i][i] = ti;
+        __syncthreads();
+    }
+    // Yc[c, j] = conj( sum_{k >= j} T[j, k] Z[k, c] ),  Z[k, c] = Zt[c + k n]
+    for (int e = t; e < ncols * KB_NB; e += blockDim.x) {
+        const int c = e % ncols, j = e / ncols;
+        cd acc = czero();
+        for (int k = j; k < KB_NB; ++k) cfma(acc, T[j][k], Zt[c + (size_t)k * g.n]);
+        Yc[c + (size_t)j * g.n] = conj(acc);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wy_update(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
+                                                    double* varena, int mode, int step, int nmat) {
+    const int z = blockIdx.z % nmat;
+    const KbItem it = items[perm[blockIdx.z / nmat]];
+    WyGeom g;
+    if (!wy_geom(it, arena, varena, mode, z, g)) return;
+    int kb, p0;
+    if (!wy_block(g, step, kb, p0)) return;
+    const int nrows = g.n - p0, ncols = g.n - p0;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    if (r0 >= nrows || c0 >= ncols) return;
+    const cd* Yc = g.ws + KB_NB * (size_t)g.n;
+    mfma_tile_k<false>(
+        [&](int i, int j) -> cd { return (j < KB_NB) ? wy_v(g, p0 + r0 + i, kb + j) : czero(); },
+        [&](int i, int j) -> cd { return (j < KB_NB && c0 + i < ncols) ? Yc[(c0 + i) + (size_t)j * g.n] : czero(); },
+        [&](int i, int jx) -> cd* {
+            const int r = r0 + i, c = c0 + jx;
+            return (r < nrows && c < ncols) ? &g.Out[(p0 + r) + (size_t)(p0 + c) * g.n] : nullptr;
+        },
+        KB_NB / KB_TU_KC);
 }
 
 // Bidiagonal QR iteration, part 1: one wavefront per item runs the scalar recurrence on

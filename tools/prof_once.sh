@@ -3,4 +3,4 @@
 TAG=${1:-t}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rm -rf $OUT/${TAG}_trace
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_trace.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_trace.log
