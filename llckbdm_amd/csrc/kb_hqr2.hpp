@@ -446,6 +446,15 @@ KB_HD void team2_helper_main(const C& ctx, Team2<C>& tm) {
 //     the barrier).  A bulge that enters at row l reads its start vector from the window image in phase 2 of the
 //     interval before;
 //   * window addresses are lane-constant plus compile-time offsets (W is a template parameter).
+// value of lane LN of the caller's half-wavefront (32 lanes), through the LDS crossbar (no LDS memory, no bank conflicts)
+template <int LN>
+__device__ __forceinline__ cd half_bcast(cd v) {
+    constexpr int PAT = (LN << 5);                      // bit mode: and_mask 0, or_mask LN, xor_mask 0
+    const int a = __builtin_amdgcn_ds_swizzle(__double2loint(v.x), PAT), b = __builtin_amdgcn_ds_swizzle(__double2hiint(v.x), PAT);
+    const int c = __builtin_amdgcn_ds_swizzle(__double2loint(v.y), PAT), d = __builtin_amdgcn_ds_swizzle(__double2hiint(v.y), PAT);
+    return mk(__hiloint2double(b, a), __hiloint2double(d, c));
+}
+
 template <int W>
 __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, Refl3* logv, const cd* sh, cd* core, int l,
                                                      int i, int nb, int t0, int t1, int ws, int we, int bmin, MsStats* stats) {
@@ -468,7 +477,7 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
     cd r_tau = czero(), r_v2 = czero(), r_v3 = czero();     // the reflector of the current interval (plain registers:
                                                             // a struct here ends up in scratch memory)
     double beta = 0.0;
-    cd* cs = core + bl * 4;
+    (void)core;
     auto refl_from_window = [&](int t) {
         const int p = l + t - 3 * b;
         const bool three = p + 2 <= i;
@@ -534,6 +543,7 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
         ctx.sync();
         if (prof) c2 = KB_CLOCK();
         // ---- phase 2: columns p..p+2, rows ws..min(p+3, i)
+        cd ynew = czero();                                // the lane's new column-p entry (near wavefronts)
         {
             const int rmax = (p + 3 < i) ? p + 3 : i;
             if (near_w) {
@@ -544,7 +554,7 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
                     apply3v<1>(r_tau, r_v2, r_v3, y0, y1, y2);
                     a[0] = y0; a[WP] = y1;
                     if (three) a[2 * WP] = y2;
-                    if (hl >= 29) cs[hl - 29] = y0;
+                    ynew = y0;
                 }
             } else if (__builtin_amdgcn_ballot_w64(act && p - 29 >= ws) != 0) {
                 const int r = p - 60 + hl;                // rows p-60 .. p-29
@@ -562,10 +572,11 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
         // ---- the reflector of interval t + 1 (near wavefronts), published in the log
         if (near_w && t + 1 < t1) {
             const bool nxt = active(t + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
+            // rows p+1..p+3 of the new column p sit in lanes 29..31 of the half: broadcast them (LDS crossbar)
+            cd a0 = half_bcast<29>(ynew), a1 = half_bcast<30>(ynew), a2 = half_bcast<31>(ynew);
             if (nxt && act) {
-                cd a0 = cs[0], a1 = cs[1], a2 = (p + 3 <= i) ? cs[2] : czero(), tau;
+                cd tau;
+                if (p + 3 > i) a2 = czero();
                 larfg3(a0, a1, a2, tau);
                 r_tau = tau; r_v2 = a1; r_v3 = a2;
                 beta = a0.x;
