@@ -717,17 +717,19 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
                     const cd rsub = kb_bcast(cur[cj], lp);        // B(j+1, j) = H(j+1, j)
                     cd cpiv = kb_bcast(cand[cj], lp);             // diagonal of the candidate
                     const cd bp = kb_bcast(bv[cj], lp);
-                    cd f, piv;
+                    // one complex reciprocal (v_rcp_f64 + two Newton steps on |piv|^2) and two products instead of two
+                    // Smith divisions: the pivots are O(||H||) .. eps3 = O(ulp ||H||), far from the range limits of |.|^2
                     const bool swap = cabs1(cpiv) < cabs1(rsub);
-                    if (!swap) {
-                        if (is_zero(cpiv)) cpiv = mk(eps3, 0.0);
-                        piv = cpiv;
-                        f = cdiv(rsub, cpiv);
-                    } else {
-                        piv = rsub;
-                        f = cdiv(cpiv, rsub);
-                    }
-                    const cd yj1 = cdiv(bp, piv);
+                    if (!swap && is_zero(cpiv)) cpiv = mk(eps3, 0.0);
+                    const cd piv = swap ? rsub : cpiv;
+                    const cd oth = swap ? cpiv : rsub;
+                    const double d2 = fma(piv.x, piv.x, piv.y * piv.y);
+                    double rr = __builtin_amdgcn_rcp(d2);
+                    rr = rr * fma(-d2, rr, 2.0);
+                    rr = rr * fma(-d2, rr, 2.0);
+                    const cd pinv = mk(piv.x * rr, -piv.y * rr);
+                    const cd f = oth * pinv;
+                    const cd yj1 = bp * pinv;
 #pragma unroll
                     for (int c = 0; c <= cj; ++c) {
                         const int r = lane + 64 * c;

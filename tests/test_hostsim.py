@@ -138,3 +138,48 @@ def test_pipeline_matches_reference_golden(hs, golden, name):
     if name == "m100":
         truth = golden["params_sorted"]
         assert_lines_close(genuine_rows(kept, truth), genuine_rows(want, truth), rel=1e-8, phase_abs=1e-8)
+
+
+def test_second_generation_qr_iteration_host_form(hs):
+    """kb_hqr2.hpp on the host context: double-shift bulges (3-element reflectors, 2 nb shifts per sweep), the
+    time-major log, strip units and the team split (helper's share inline).  Eigenvalues against LAPACK, solo and team
+    bit-identical, protocol counters consistent, and fewer chase intervals than the single-shift iteration of round 1
+    on a reduced KBDM matrix (the point of the double-shift bulges)."""
+    rng = np.random.default_rng(9)
+    hs.hs_eigvals2.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, ctypes.c_int]
+
+    def run2(W, nb, win, team):
+        n = W.shape[0]
+        Wf = np.asfortranarray(W)
+        mu, st = np.zeros(n, complex), np.zeros(16, np.int64)
+        info = hs.hs_eigvals2(Wf.ctypes.data_as(P), n, nb, win, team, mu.ctypes.data_as(P), st.ctypes.data_as(P), 0)
+        return info, mu, st
+
+    for n, nb, win in ((3, 8, 56), (9, 8, 56), (13, 8, 56), (40, 4, 32), (70, 8, 56), (130, 8, 56), (90, 2, 24)):
+        W = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        i_s, mu_s, st_s = run2(W, nb, win, 0)
+        i_t, mu_t, st_t = run2(W, nb, win, 1)
+        assert i_s == 0 and i_t == 0
+        assert np.array_equal(mu_s, mu_t)
+        ref = np.linalg.eigvals(W)
+        assert np.abs(mu_s[:, None] - ref[None, :]).min(axis=1).max() < 1e-11 * n
+        assert len(set(np.abs(mu_s[:, None] - ref[None, :]).argmin(axis=1))) == n          # every eigenvalue exactly once
+        published, all_done, done, near_done = (int(x) for x in st_t[4:8])
+        assert published == st_t[3] and all_done == published and near_done == published and done == 1
+    # a reduced KBDM matrix (the shape the kernel sees): Hankel signal -> SVD -> projected U^1
+    import scipy.linalg as sla
+    from oracle import kbdm_oracle as O
+    sig = O.make_noisy(O.brain_sim_signal(1024), 1e-3, 0)
+    m = 150
+    U0, Up1, Up = O.compute_U_matrices(sig, m, 1)
+    L, s, Rh = sla.svd(Up1)
+    D = np.diag(1 / np.sqrt(s))
+    W = D @ L.conj().T @ Up @ Rh.conj().T @ D
+    info, mu, st = run2(W, 8, 56, 0)
+    assert info == 0
+    ref = np.linalg.eigvals(W)
+    assert np.abs(mu[:, None] - ref[None, :]).min(axis=1).max() < 1e-11 * np.abs(ref).max() * m
+    mu1, st1 = np.zeros(m, complex), np.zeros(8, np.int64)
+    Wf = np.asfortranarray(W)
+    assert hs.hs_eigvals_ms(Wf.ctypes.data_as(P), m, 8, 56, mu1.ctypes.data_as(P), st1.ctypes.data_as(P)) == 0
+    assert st[0] < 0.85 * st1[0], (int(st[0]), int(st1[0]))          # chase intervals: double-shift vs single-shift bulges
