@@ -378,12 +378,14 @@ __global__ void __launch_bounds__(256) k_wy_gram(const KbItem* __restrict__ item
 
 __global__ void __launch_bounds__(256) k_wy_t(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
                                                double* varena, int mode, int step) {
-    const KbItem it = items[perm[blockIdx.x]];
+    const KbItem it = items[perm[blockIdx.y]];
     WyGeom g;
-    if (!wy_geom(it, arena, varena, mode, blockIdx.y, g)) return;
+    if (!wy_geom(it, arena, varena, mode, blockIdx.z, g)) return;
     int kb, p0;
     if (!wy_block(g, step, kb, p0)) return;
     const int ncols = g.n - p0;
+    const int c0 = blockIdx.x * 64;
+    if (c0 >= ncols) return;
     const cd* Zt = g.ws;
     cd* Yc = g.ws + KB_NB * (size_t)g.n;
     const cd* Gt = g.ws + 2 * KB_NB * (size_t)g.n;
@@ -392,7 +394,8 @@ __global__ void __launch_bounds__(256) k_wy_t(const KbItem* __restrict__ items, 
     const int t = threadIdx.x;
     for (int e = t; e < KB_NB * (KB_NB + 1); e += blockDim.x) (&T[0][0])[e] = czero();
     __syncthreads();
-    // zlarft, forward / columnwise: T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i;  G(l, i) = Gt[i + l NB]
+    // zlarft, forward / columnwise: T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i;  G(l, i) = Gt[i + l NB].
+    // (every column tile of the member repeats these 32 short steps: cheaper than another launch)
     for (int i = 0; i < KB_NB; ++i) {
         const cd ti = (kb + i < g.nref) ? g.tau[kb + i] : czero();
         if (t < i) col[t] = -(ti * Gt[i + t * KB_NB]);
@@ -405,13 +408,12 @@ __global__ void __launch_bounds__(256) k_wy_t(const KbItem* __restrict__ items, 
         if (t == i) T[i][i] = ti;
         __syncthreads();
     }
-    // Yc[c, j] = conj( sum_{k >= j} T[j, k] Z[k, c] ),  Z[k, c] = Zt[c + k n]
-    for (int e = t; e < ncols * KB_NB; e += blockDim.x) {
-        const int c = e % ncols, j = e / ncols;
-        cd acc = czero();
-        for (int k = j; k < KB_NB; ++k) cfma(acc, T[j][k], Zt[c + (size_t)k * g.n]);
-        Yc[c + (size_t)j * g.n] = conj(acc);
-    }
+    // Yc[c, j] = conj( sum_k T[j, k] Z[k, c] ) = sum_k conj(Zt[c, k]) conj(T[j, k]):  one 64 x 32 MFMA tile, k = NB
+    mfma_tile_k<true>(
+        [&](int i, int k) -> cd { return (k < KB_NB && c0 + i < ncols) ? conj(Zt[(c0 + i) + (size_t)k * g.n]) : czero(); },
+        [&](int j, int k) -> cd { return (j < KB_NB && k < KB_NB) ? T[j][k] : czero(); },
+        [&](int i, int j) -> cd* { return (j < KB_NB && c0 + i < ncols) ? &Yc[(c0 + i) + (size_t)j * g.n] : nullptr; },
+        KB_NB / KB_TU_KC);
 }
 
 __global__ void __launch_bounds__(256) k_wy_update(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
