@@ -151,6 +151,7 @@ struct Team2 {
     int failed;
     HSc1 A;
     int W;
+    int ws_last[2] = {0x3fffffff, 0x3fffffff};     // first rows of the windows of the last two records
 };
 
 // ---- strip units.  Right unit u: columns we + 8 u .. + 7 (not beyond i), row operations on the window's rows.
@@ -596,6 +597,11 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
 }
 #endif
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host simulation only (tests/hostsim): called after every window step with its geometry
+inline void (*kb2_host_trace)(const Win2Geom& G, int team, int phase) = nullptr;
+#endif
+
 // ---- windowed chase of nb double-shift bulges (shifts sh[2b], sh[2b+1] drive bulge b).
 template <class C, class ACC>
 KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, const cd* sh, int W, const Hqr2Lds& L,
@@ -609,7 +615,20 @@ KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, con
     Refl3* logv = L.logv;
     const int T = (na - 1) + 3 * (nb - 1);
     int t0 = 0;
-    if (team) team->g_batch = team->g;
+    if (team) {
+        Team2<C>& tm = *team;
+        tm.g_batch = tm.g;
+        // The helper may still be working on the last two steps of the sweep before (everything older is complete: the
+        // chase workgroup waited for near_done at its last step).  Their far right units and top units lie in the columns
+        // from their window's first row on: when that reaches into the first window of THIS sweep (small active blocks;
+        // the exceptional-shift path gets here within a few microseconds), the window must not be loaded before the
+        // helper is through.
+        const int wsmin = tm.ws_last[0] < tm.ws_last[1] ? tm.ws_last[0] : tm.ws_last[1];
+        if (tm.g > 0 && !tm.failed && wsmin < l + W) {
+            if (!team_wait(ctx, &tm.ctl->all_done, tm.g, tm.ctl, L.flag)) tm.failed = 1;
+        }
+        if (tm.failed) return;
+    }
     while (t0 < T) {
         // ---- window of this step: first row = row above the topmost active bulge
         int bh0 = t0 / 3;
@@ -772,6 +791,8 @@ KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, con
             (void)rec;
 #endif
             team_signal(ctx, &tm.ctl->published, tm.g + 1);
+            tm.ws_last[0] = tm.ws_last[1];
+            tm.ws_last[1] = ws;
         }
         // ---- (c) store the window back
         for (int idx = tid; idx < wlen * wlen; idx += nt) {
@@ -804,6 +825,9 @@ KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, con
             tm.g++;
         }
         ctx.sync();
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if (kb2_host_trace) kb2_host_trace(G, team != nullptr, 0);
+#endif
         if (stats && tid == 0) {
             const long long c_e = KB_CLOCK();
             stats->small_steps++;

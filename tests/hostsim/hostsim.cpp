@@ -7,6 +7,7 @@
 // by the llckbdm_amd package (which talks to the HIP library only and fails loudly
 // without it).
 #include <complex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -227,6 +228,19 @@ int hs_eigvals_team(const double* W_in, int n, int nsmax, int win_w, double* mu_
     return info;
 }
 
+// Debug trace of the second-generation iteration: one line per window step (geometry + a checksum of H) into the
+// file named by HS_TRACE.
+static FILE* g_trace = nullptr;
+static const cd* g_trace_H = nullptr;
+static int g_trace_n = 0;
+static void hs_trace_step(const Win2Geom& G, int team, int) {
+    if (!g_trace) return;
+    double s1 = 0, s2 = 0;
+    for (size_t k = 0; k < (size_t)g_trace_n * g_trace_n; ++k) { s1 += g_trace_H[k].x * (1 + (k % 7)); s2 += g_trace_H[k].y * (1 + (k % 5)); }
+    fprintf(g_trace, "l %d i %d nb %d t0 %d t1 %d ws %d we %d bmin %d bmax %d near %d team %d sum %.17g %.17g\n", G.l, G.i, G.nb, G.t0, G.t1,
+            G.ws, G.we, G.bmin, G.bmax, G.nr_near, team, s1, s2);
+}
+
 // Second-generation QR iteration (kb_hqr2.hpp): double-shift bulges, time-major log, strip units.
 // team != 0 runs the chase-workgroup / helper-workgroup split with the helper's share inline.
 int hs_eigvals2(const double* W_in, int n, int nbmax, int win_w, int team, double* mu_out, long long* stats_out, int smode) {
@@ -249,7 +263,11 @@ int hs_eigvals2(const double* W_in, int n, int nbmax, int win_w, int team, doubl
     tm.g = 0; tm.g_batch = 0; tm.failed = 0;
     tm.A = HSc1::make(Hc.data(), n, n);
     tm.W = win_w;
+    if (const char* tf = getenv("HS_TRACE")) {
+        g_trace = fopen(tf, "w"); g_trace_H = Hc.data(); g_trace_n = n; kb2_host_trace = hs_trace_step;
+    }
     hqr2_eigvals(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nbmax, win_w, &st, team ? &tm : nullptr, smode);
+    if (g_trace) { fclose(g_trace); g_trace = nullptr; kb2_host_trace = nullptr; }
     if (stats_out) {
         stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps;
         stats_out[4] = ctl.published; stats_out[5] = ctl.all_done; stats_out[6] = ctl.done; stats_out[7] = ctl.near_done;

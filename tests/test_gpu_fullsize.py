@@ -18,10 +18,12 @@ def eng():
     e.close()
 
 
-def _check(eng, sigs, sig_idx, ms, nsample=24, oracle_members=(), truth=None):
+def _check(eng, sigs, sig_idx, ms, nsample=24, oracle_members=(), truth=None, strict_status=False):
     from llckbdm_amd import datasets
     res = eng.solve(sigs, sig_idx, ms, None, p=1, q=0.0, dwell=datasets.DWELL)
     assert not (res.status & 3).any()                 # SVD / eigenvalue iteration converged everywhere
+    if strict_status:                                 # ... and no inverse iteration was flagged weak
+        assert not res.status.any(), [(int(ms[i]), int(res.status[i])) for i in np.nonzero(res.status)[0]]
     B = len(ms)
     rng = np.random.default_rng(0)
     pick = sorted(set([0, B - 1] + [int(x) for x in rng.integers(0, B, nsample)]))
@@ -78,5 +80,7 @@ def test_config4_full_m200_to_1200_N4096(eng):
     from llckbdm_amd import datasets
     sigs, sig_idx, ms = datasets.config4()
     assert len(ms) == 1001 and sigs.shape == (1, 4096) and ms[-1] == 1200
-    # m = 200, 700 and 1200 (the oracle needs ~10 s for the largest)
-    _check(eng, sigs, sig_idx, ms, nsample=12, oracle_members=(0, 500, 1000))
+    # m = 200, 700, 1123 and 1200 (the oracle needs ~10 s for the largest).  m = 1123 is the member whose QR iteration
+    # once read a window before the helper workgroup had finished the sweep before (exceptional-shift path on a small
+    # active block): eigenvalues off by 1e-5 and only the inverse iteration's flag raised - hence the strict status.
+    _check(eng, sigs, sig_idx, ms, nsample=12, oracle_members=(0, 500, 923, 1000), strict_status=True)
