@@ -108,6 +108,8 @@ struct kbdm_ctx {
                           // 0 = one workgroup per member, N = fixed
     int gen_wy = 1;       // explicit Q / P / Qh of large members by blocked compact-WY accumulation on MFMA (0: k_gen for all)
     int blocked = 1;      // blocked (panel + MFMA update) reductions; 0: unblocked kernels only (debugging)
+    int stream_wpb = 1;   // KBDM_STREAM_WPB: row blocks (wavefronts) per workgroup of the rotation replay
+    int bidiag_fused = 0; // KBDM_BIDIAG_FUSED=1: one pass over the trailing matrix per panel column (members up to 512 rows)
     int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
     int hqr_v = 2;        // QR iteration: 2 = kb_hqr2.hpp (double-shift bulges, systolic strips), 1 = round-1 kernels
     int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
@@ -169,7 +171,8 @@ size_t item_arena_elems(int m, int l) {
 
 int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svd_fac), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_gen), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_sort), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
@@ -381,11 +384,18 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     {
         // blocked part: panels + MFMA trailing updates (all inside the "k_svd_fac" stage timer)
         const int npan = ctx->blocked ? bidiag_num_panels(ch.mmax) : 0;
-        const int smp = KB_RED_BYTES + bidiag_panel_scratch_bytes(ch.mmax, ctx->nt_fac / 64, 64);
+        int smp = KB_RED_BYTES + bidiag_panel_scratch_bytes(ch.mmax, ctx->nt_fac / 64, 64);
+        // one-pass panels (bidiag_panel_fused): a column in 8 register chunks and nwaves row accumulators in LDS
+        const int smf = KB_RED_BYTES + bidiag_panel_fused_scratch_bytes(ch.mmax, KB_PANEL_FUSED_NT / 64);
+        const int fused = (ctx->bidiag_fused && ch.mmax <= KB_PANEL_FUSED_MAXC * 64 && smf <= LDS_MAX) ? 1 : 0;
         if (npan > 0 && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
         for (int pnl = 0; pnl < npan; ++pnl) {
-            hipLaunchKernelGGL(k_bidiag_panel, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
-                               pl->d_arena, pl->d_varena, pnl, smp);
+            if (fused)
+                hipLaunchKernelGGL(k_bidiag_panel<1>, dim3(ch.count), dim3(KB_PANEL_FUSED_NT), smf, st, pl->d_items, perm,
+                                   pl->d_arena, pl->d_varena, pnl, smf);
+            else
+                hipLaunchKernelGGL(k_bidiag_panel<0>, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
+                                   pl->d_arena, pl->d_varena, pnl, smp);
             const int nn = ch.mmax - (pnl + 1) * KB_NB;
             const int tiles = (nn + 63) / 64;
             hipLaunchKernelGGL(k_trail_update, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
@@ -424,7 +434,9 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     {
         // Rotation replay (streaming, no LDS): one launch for the whole chunk; with the in-kernel hand-off
         // its wavefronts follow the generators set by set.
-        hipLaunchKernelGGL(k_bdsqr_stream, dim3((2 * ch.mmax + 63) / 64, ch.count, 2), dim3(64), 0, st, pl->d_items,
+        const int wpb = std::min(16, std::max(1, ctx->stream_wpb));             // wavefronts (row blocks) per workgroup
+        const int nrb = (2 * ch.mmax + 63) / 64;
+        hipLaunchKernelGGL(k_bdsqr_stream, dim3((nrb + wpb - 1) / wpb, ch.count, 2), dim3(64 * wpb), 0, st, pl->d_items,
                            perm, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, flag_mode ? 1 : 0, pl->d_status,
                            (unsigned)std::max(1, env_int("KBDM_BDSQR_SPIN_LIMIT", 1 << 26)));
         if (flag_mode) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
@@ -679,6 +691,8 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->blocked = env_int("KBDM_BLOCKED", c->blocked);
     c->gen_wy = env_int("KBDM_GEN_WY", c->gen_wy);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
+    c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
+    c->stream_wpb = env_int("KBDM_STREAM_WPB", c->stream_wpb);
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
     c->win_hqr2 = std::min(64, std::max(3 * c->nb_hqr2 + 8, env_int("KBDM_WIN_HQR2", c->win_hqr2)));
     if (c->ns_hqr > KB_MS_NSMAX) c->ns_hqr = KB_MS_NSMAX;

@@ -76,11 +76,13 @@ __global__ void __launch_bounds__(256) k_hankel(const KbItem* __restrict__ items
 // ------------------------------------------------------------------------------------
 // Householder bidiagonalisation, blocked: for panel p = 0, 1, ... (host loop)
 //   k_bidiag_panel  one workgroup per item: NB reflector pairs, X/Y panels (Q and P buffers are
-//                   free at this point), two matrix-vector products with the trailing matrix per column
+//                   free at this point); the two matrix-vector products with the trailing matrix per column
+//                   share ONE pass over it (bidiag_panel_fused) for members of at most 512 rows
 //   k_trail_update  all CUs: A0[NB:, NB:] -= [V | X] [Y | U]^H  with FP64 MFMA 16x16x4 tiles
 // then k_svd_fac finishes the last (< NB + NX) columns unblocked.
 // Left vectors stay in A, right vectors go to the R buffer (free until the sort).
-__global__ void __launch_bounds__(1024) k_bidiag_panel(const KbItem* __restrict__ items, const int* __restrict__ perm,
+template <int FUSED>
+__global__ void __launch_bounds__(FUSED ? KB_PANEL_FUSED_NT : 1024) k_bidiag_panel(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                         cd* arena, double* varena, int panel, int smem_bytes) {
     const KbItem it = items[perm[blockIdx.x]];
     const int m = it.m;
@@ -96,7 +98,10 @@ __global__ void __launch_bounds__(1024) k_bidiag_panel(const KbItem* __restrict_
     double* e = dv + KB_V_E * it.vstride + p0;
     cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride) + p0;
     cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride) + p0;
-    bidiag_panel(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
+    // FUSED: one pass over the trailing matrix per column (the host launches it when a column fits the register chunks
+    // and sizes the scratch for it)
+    if (FUSED) bidiag_panel_fused<DevCtx, KB_PANEL_FUSED_MAXC>(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
+    else bidiag_panel(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
 }
 
 // Rank-64 update of one 64 x 64 tile of C on FP64 MFMA:  C[r, c] -= sum_k Aop(r, k) conj(Bop(c, k)), k < 2 NB.
@@ -464,14 +469,18 @@ __global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ ite
 // Part 2: the logged rotations are applied to the rows of Q (blockIdx.z = 0) and P (= 1): one lane per
 // real component of a row, rows pass through a register
 // window (bdsqr_stream_lane), no LDS, so many wavefronts share a SIMD.  grid (ceil(2 m / 64), members, 2).
-__global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                      cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
-                                                      int* iwork, int wait_flag, int* status, unsigned spin_limit) {
+__global__ void __launch_bounds__(1024) k_bdsqr_stream(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                        cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
+                                                        int* iwork, int wait_flag, int* status, unsigned spin_limit) {
+    // blockDim.x / 64 independent wavefronts per workgroup (no barrier, no LDS): row block = one wavefront.  Many
+    // wavefronts per workgroup keep the long-lived replay on few CUs instead of a wavefront or two on every CU, where
+    // they would stand in the way of the workgroups that need a whole CU's registers (panels, QR iteration).
     const int item = perm[blockIdx.y];
     const KbItem it = items[item];
     const int m = it.m;
-    if ((int)blockIdx.x * 64 >= 2 * m) return;
-    const int vl = blockIdx.x * 64 + threadIdx.x;
+    const int rb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // row block of this wavefront
+    if (rb * 64 >= 2 * m) return;
+    const int vl = rb * 64 + (threadIdx.x & 63);
     const bool live = vl < 2 * m;
     double* X = reinterpret_cast<double*>(arena + it.off[blockIdx.z == 0 ? KB_BUF_Q : KB_BUF_P]);
     const RotBatch* hdr0 = hdr_all + it.hdr_off;
@@ -497,7 +506,7 @@ __global__ void __launch_bounds__(64) k_bdsqr_stream(const KbItem* __restrict__ 
             if (++spins > spin_limit) {
                 // generator lost (it never became resident: streams sharing a hardware queue, or it died): this member's
                 // Q / P stay un-replayed - flag the member, never return a silent answer
-                if (threadIdx.x == 0) atomicOr(&status[item], KB_STAT_SVD_NOCONV);
+                if ((threadIdx.x & 63) == 0) atomicOr(&status[item], KB_STAT_SVD_NOCONV);
                 return;
             }
             __builtin_amdgcn_s_sleep(32);

@@ -37,7 +37,10 @@ static void hs_bidiag_blocked(HostCtx& ctx, int m, cd* A, double* d, double* e, 
         const int p0 = p * KB_NB, n = m - p0;
         cd* Ab = A + p0 + (size_t)p0 * m;
         cd* Ub = UR + p0 + (size_t)p0 * m;
-        bidiag_panel(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
+        // HS_BIDIAG_FUSED=0: the two-pass panel (what members above 512 rows get on the device)
+        const char* fz = getenv("HS_BIDIAG_FUSED");
+        if (fz && atoi(fz) == 0) bidiag_panel(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
+        else bidiag_panel_fused<HostCtx, HS_MAXC>(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
         for (int c = KB_NB; c < n; ++c)
             for (int r = KB_NB; r < n; ++r) {
                 cd acc = Ab[r + (size_t)c * m];
@@ -57,7 +60,7 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
     std::vector<double> d(m), e(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) + 4 * m);
+    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) + 4 * m);
     hs_bidiag_blocked(ctx, m, A.data(), d.data(), e.data(), tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
@@ -80,7 +83,7 @@ int hs_svd_stream(const double* A_in, int m, double* L_out, double* s_out, doubl
     std::vector<double> d(m), e(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) + 4 * m);
+    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) + 4 * m);
     hs_bidiag_blocked(ctx, m, A.data(), d.data(), e.data(), tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
@@ -107,7 +110,7 @@ int hs_bidiag(const double* A_in, int m, double* d, double* e, double* Q_out, do
     std::vector<cd> A(m * m), UR(m * m), tq(m), tp(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_scratch_bytes(m, 1, 1));
+    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1));
     hs_bidiag_blocked(ctx, m, A.data(), d, e, tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), reinterpret_cast<cd*>(Q_out), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), reinterpret_cast<cd*>(P_out), m, 0, m);

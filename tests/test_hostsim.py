@@ -183,3 +183,27 @@ def test_second_generation_qr_iteration_host_form(hs):
     Wf = np.asfortranarray(W)
     assert hs.hs_eigvals_ms(Wf.ctypes.data_as(P), m, 8, 56, mu1.ctypes.data_as(P), st1.ctypes.data_as(P)) == 0
     assert st[0] < 0.85 * st1[0], (int(st[0]), int(st1[0]))          # chase intervals: double-shift vs single-shift bulges
+
+
+def test_one_pass_bidiagonalisation_panel_matches_two_pass(hs):
+    """bidiag_panel_fused (one pass over the trailing matrix per column: the row accumulators of A0 rr ride along with the
+    column dots of y) against the two-pass panel: same bidiagonal to rounding, A = Q B P^H, unitary factors."""
+    rng = np.random.default_rng(21)
+    for m in (96, 130, 203):
+        A = np.asfortranarray(rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
+        out = {}
+        for fused in (0, 1):
+            os.environ["HS_BIDIAG_FUSED"] = str(fused)
+            d, e = np.zeros(m), np.zeros(m)
+            Q, Pm = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F")
+            assert hs.hs_bidiag(A.ctypes.data_as(P), m, d.ctypes.data_as(P), e.ctypes.data_as(P), Q.ctypes.data_as(P),
+                                Pm.ctypes.data_as(P)) == 0
+            out[fused] = (d.copy(), e.copy(), Q.copy(), Pm.copy())
+        os.environ.pop("HS_BIDIAG_FUSED")
+        d0, e0, Q0, P0 = out[0]
+        d1, e1, Q1, P1 = out[1]
+        nrm = np.linalg.norm(A, 2)
+        assert np.abs(d0 - d1).max() < 1e-13 * nrm and np.abs(e0 - e1).max() < 1e-13 * nrm
+        B = np.diag(d1) + np.diag(e1[:m - 1], 1)
+        assert np.abs(Q1 @ B @ P1.conj().T - A).max() < 1e-13 * nrm
+        assert np.abs(Q1.conj().T @ Q1 - np.eye(m)).max() < 1e-13 and np.abs(P1.conj().T @ P1 - np.eye(m)).max() < 1e-13
