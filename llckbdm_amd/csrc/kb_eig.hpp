@@ -644,8 +644,9 @@ KB_HD void invit(const C& ctx, int n, const cd* H, int ldh, const cd* w, double 
 // Register-resident inverse iteration (device only): the same elimination and the same arithmetic as
 // `invit` above, but the three O(n) vectors of a solve (candidate column, right-hand side, multipliers) live
 // in the REGISTERS of the wavefront - element r on lane r mod 64, chunk r / 64 - instead of LDS: a value at a
-// known position is broadcast with v_readlane, no LDS traffic, no fences, and no LDS footprint, so many
-// wavefronts share a CU (the LDS form holds 19 KB per solve at n = 400: eight wavefronts per CU).
+// known position is broadcast with v_readlane, no fences (the LDS form holds 19 KB per solve at n = 400).  Only the
+// multipliers f_j, written once per step by one lane and read back by the serial substitution chain, sit in LDS
+// (fmL: MAXC * 64 entries per wavefront).
 // The chunk of the pivot position is a compile-time index (outer loops over chunks are unrolled), so every
 // register access is static.  n <= MAXC * 64.
 __device__ __forceinline__ cd kb_bcast(cd v, int l) {
@@ -653,9 +654,113 @@ __device__ __forceinline__ cd kb_bcast(cd v, int l) {
               __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.y), l), __builtin_amdgcn_readlane(__double2loint(v.y), l)));
 }
 
+// One elimination step of invit_reg (position p: column j = p - 1 is eliminated against the candidate at p).  The chunk
+// CJ of row p is a compile-time index; LP0 marks the one step per chunk whose row j lies in the chunk below (p = 64 CJ).
+// What is wavefront-uniform is decided by scalar branches (the pivot choice) or known at compile time (which chunks are
+// full, where the diagonal / the new y / the multiplier go), so the vector part of a chunk is eight FMAs.
+__device__ __forceinline__ cd csel2(bool c, cd a, cd b) { return mk(c ? a.x : b.x, c ? a.y : b.y); }
+
+template <int MAXC>
+struct InvitRegState {
+    cd cand[MAXC], bv[MAXC], nxt[MAXC];
+    cd* fmL;                                                  // multipliers f_j of this solve: LDS, MAXC * 64 entries per wavefront
+    unsigned swp;
+    bool rescaled;
+    cd wk;
+    double eps3;
+    const cd* __restrict__ H;
+    int ldh, lane;
+
+    template <int CJ, bool LP0>
+    __device__ __forceinline__ void step(int p) {
+        constexpr int CK = LP0 ? CJ - 1 : CJ;                 // chunk of row j
+        const int j = p - 1;
+        const int lp = LP0 ? 0 : p - 64 * CJ;                 // lane of row p (chunk CJ)
+        const int lj = LP0 ? 63 : lp - 1;                     // lane of row j (chunk CK)
+        cd cur[MAXC];
+#pragma unroll
+        for (int c = 0; c <= CJ; ++c) cur[c] = nxt[c];
+        if (j >= 1) {                                          // raw column j - 1, rows <= j, for the next step
+            const cd* __restrict__ Hc = H + (size_t)(j - 1) * ldh + lane;
+#pragma unroll
+            for (int c = 0; c < CK; ++c) nxt[c] = Hc[64 * c];
+            nxt[CK] = (LP0 || lane <= lj) ? Hc[64 * CK] : czero();
+        }
+        const cd rsub = kb_bcast(cur[CJ], lp);                // B(j+1, j) = H(j+1, j)
+        cd cpiv = kb_bcast(cand[CJ], lp);                     // diagonal of the candidate
+        const cd bp = kb_bcast(bv[CJ], lp);
+        // one complex reciprocal (v_rcp_f64 + two Newton steps on |piv|^2) and two products instead of two Smith
+        // divisions: the pivots are O(||H||) .. eps3 = O(ulp ||H||), far from the range limits of |.|^2
+        const bool swap = __builtin_amdgcn_readfirstlane((int)(cabs1(cpiv) < cabs1(rsub))) != 0;
+        if (!swap && is_zero(cpiv)) cpiv = mk(eps3, 0.0);
+        const cd piv = swap ? rsub : cpiv;
+        const cd oth = swap ? cpiv : rsub;
+        const double d2 = fma(piv.x, piv.x, piv.y * piv.y);
+        double rr = __builtin_amdgcn_rcp(d2);
+        rr = rr * fma(-d2, rr, 2.0);
+        rr = rr * fma(-d2, rr, 2.0);
+        const cd pinv = mk(piv.x * rr, -piv.y * rr);
+        const cd f = oth * pinv;
+        const cd yj1 = bp * pinv;
+        {                                                      // the diagonal entry of the raw column: B(j, j) = H(j, j) - w
+            const bool dj = lane == lj;
+            cur[CK] = mk(dj ? cur[CK].x - wk.x : cur[CK].x, dj ? cur[CK].y - wk.y : cur[CK].y);
+        }
+        const bool top = LP0 || lane <= lj;                    // rows <= j of chunk CK
+        if (swap) {                                            // the raw column is final at position j + 1
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const cd raw = cur[c];
+                cand[c] = cand[c] - f * raw;
+                bv[c] = bv[c] - yj1 * raw;
+            }
+            const cd raw = cur[CK];
+            const cd nc = cand[CK] - f * raw, nb = bv[CK] - yj1 * raw;
+            cand[CK] = csel2(top, nc, cand[CK]);
+            bv[CK] = csel2(top, nb, bv[CK]);
+        } else {                                               // the candidate is
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const cd cn = cand[c];
+                cand[c] = cur[c] - f * cn;
+                bv[c] = bv[c] - yj1 * cn;
+            }
+            const cd cn = cand[CK];
+            const cd nc = cur[CK] - f * cn, nb = bv[CK] - yj1 * cn;
+            cand[CK] = csel2(top, nc, cn);
+            bv[CK] = csel2(top, nb, bv[CK]);
+        }
+        bv[CJ] = csel2(lane == lp, yj1, bv[CJ]);              // y at row p
+        if (lane == 0) fmL[j] = f;
+        if (lane == lj) swp = swap ? (swp | (1u << CK)) : (swp & ~(1u << CK));
+        if (cabs1(yj1) > 1e120) {                              // guard against overflow: rescale the whole system
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) bv[c] = bv[c] * 1e-120;
+            rescaled = true;
+        }
+    }
+
+    // all positions of chunk CJ, top down
+    template <int CJ>
+    __device__ __forceinline__ void chunk(int n) {
+        const int phi = (n - 1 < 64 * CJ + 63) ? n - 1 : 64 * CJ + 63;
+        const int plo = 64 * CJ + 1;                           // lp >= 1
+        for (int p = phi; p >= plo; --p) step<CJ, false>(p);
+        if constexpr (CJ >= 1) {
+            if (n - 1 >= 64 * CJ) step<CJ, true>(64 * CJ);
+        }
+    }
+};
+
+template <int MAXC, int CJ>
+__device__ __forceinline__ void invit_chunks(InvitRegState<MAXC>& S, int n) {
+    if (n - 1 >= 64 * CJ) S.template chunk<CJ>(n);
+    if constexpr (CJ >= 1) invit_chunks<MAXC, CJ - 1>(S, n);
+}
+
 template <int MAXC>
 __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, int ldh, const cd* __restrict__ w,
-                          double hnorm, cd* __restrict__ X, int ldx, int kk_begin, int kk_step, int* weak) {
+                          double hnorm, cd* __restrict__ X, int ldx, int kk_begin, int kk_step, int* weak, cd* fmL) {
     const int lane = ctx.lane();
     const double eps3 = fmax(hnorm * KB_ULP, KB_SAFMIN * ((double)n / KB_ULP));
     const double rootn = sqrt((double)n);
@@ -669,8 +774,11 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
             cnt = (int)ctx.wave_sum((double)cnt);
             wk.x += cnt * eps3;
         }
-        cd cand[MAXC], bv[MAXC], fm[MAXC];
-        unsigned swp = 0;                  // bit c: swap flag of element lane + 64 c
+        InvitRegState<MAXC> S;
+        cd (&cand)[MAXC] = S.cand;
+        cd (&bv)[MAXC] = S.bv;
+        unsigned& swp = S.swp;             // bit c: swap flag of element lane + 64 c
+        S.wk = wk; S.eps3 = eps3; S.H = H; S.ldh = ldh; S.lane = lane; S.fmL = fmL;
         bool ok = false;
         for (int its = 0; its < 4 && !ok; ++its) {
 #pragma unroll
@@ -687,71 +795,17 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
                 cd v = (r < n) ? H[r + (size_t)(n - 1) * ldh] : czero();
                 if (r == n - 1) v = v - wk;
                 cand[c] = v;
-                fm[c] = czero();
             }
             swp = 0;
-            bool rescaled = false;
-            cd nxt[MAXC];
+            S.rescaled = false;
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
                 const int r = lane + 64 * c;
-                nxt[c] = (n >= 2 && r <= n - 1) ? H[r + (size_t)(n - 2) * ldh] : czero();
+                S.nxt[c] = (n >= 2 && r <= n - 1) ? H[r + (size_t)(n - 2) * ldh] : czero();
             }
-            // position p = j + 1 runs from n-1 down to 1; cj = chunk of p (compile time)
-#pragma unroll
-            for (int cj = MAXC - 1; cj >= 0; --cj) {
-                const int phi = (n - 1 < 64 * cj + 63) ? n - 1 : 64 * cj + 63;
-                const int plo = (64 * cj > 1) ? 64 * cj : 1;
-                for (int p = phi; p >= plo; --p) {
-                    const int j = p - 1, lp = p - 64 * cj;
-                    cd cur[MAXC];
-#pragma unroll
-                    for (int c = 0; c <= cj; ++c) cur[c] = nxt[c];
-                    if (j >= 1) {
-#pragma unroll
-                        for (int c = 0; c <= cj; ++c) {
-                            const int r = lane + 64 * c;
-                            nxt[c] = (r <= j) ? H[r + (size_t)(j - 1) * ldh] : czero();
-                        }
-                    }
-                    const cd rsub = kb_bcast(cur[cj], lp);        // B(j+1, j) = H(j+1, j)
-                    cd cpiv = kb_bcast(cand[cj], lp);             // diagonal of the candidate
-                    const cd bp = kb_bcast(bv[cj], lp);
-                    // one complex reciprocal (v_rcp_f64 + two Newton steps on |piv|^2) and two products instead of two
-                    // Smith divisions: the pivots are O(||H||) .. eps3 = O(ulp ||H||), far from the range limits of |.|^2
-                    const bool swap = cabs1(cpiv) < cabs1(rsub);
-                    if (!swap && is_zero(cpiv)) cpiv = mk(eps3, 0.0);
-                    const cd piv = swap ? rsub : cpiv;
-                    const cd oth = swap ? cpiv : rsub;
-                    const double d2 = fma(piv.x, piv.x, piv.y * piv.y);
-                    double rr = __builtin_amdgcn_rcp(d2);
-                    rr = rr * fma(-d2, rr, 2.0);
-                    rr = rr * fma(-d2, rr, 2.0);
-                    const cd pinv = mk(piv.x * rr, -piv.y * rr);
-                    const cd f = oth * pinv;
-                    const cd yj1 = bp * pinv;
-#pragma unroll
-                    for (int c = 0; c <= cj; ++c) {
-                        const int r = lane + 64 * c;
-                        if (r <= j) {
-                            cd raw = cur[c];
-                            if (r == j) raw = raw - wk;
-                            const cd cn = cand[c];
-                            const cd fin = swap ? raw : cn;
-                            const cd oth = swap ? cn : raw;
-                            cand[c] = oth - f * fin;          // new candidate for position j
-                            bv[c] = bv[c] - yj1 * fin;
-                        }
-                        if (r == p) bv[c] = yj1;
-                        if (r == j) { fm[c] = f; swp = swap ? (swp | (1u << c)) : (swp & ~(1u << c)); }
-                    }
-                    if (cabs1(yj1) > 1e120) {                  // guard against overflow: rescale the whole system
-#pragma unroll
-                        for (int c = 0; c < MAXC; ++c) bv[c] = bv[c] * 1e-120;
-                        rescaled = true;
-                    }
-                }
-            }
+            // position p = j + 1 runs from n-1 down to 1; the chunk of p is a compile-time index
+            invit_chunks<MAXC, MAXC - 1>(S, n);
+            const bool rescaled = S.rescaled;
             {
                 cd p0 = kb_bcast(cand[0], 0);
                 if (is_zero(p0)) p0 = mk(eps3, 0.0);
@@ -763,7 +817,7 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
                     const int jhi = (n - 2 < 64 * cj + 63) ? n - 2 : 64 * cj + 63;
                     for (int j = 64 * cj; j <= jhi; ++j) {
                         const int lj = j - 64 * cj;
-                        const cd f = kb_bcast(fm[cj], lj);
+                        const cd f = fmL[j];
                         const bool sw = (__builtin_amdgcn_readlane((int)swp, lj) >> cj) & 1;
                         cd b;
                         if (lj < 63) b = kb_bcast(bv[cj], lj + 1);

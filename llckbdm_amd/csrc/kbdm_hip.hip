@@ -182,6 +182,7 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit_reg<8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     return KBDM_OK;
 }
 
@@ -575,9 +576,10 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             split = std::max(1, std::min(split, 64));
             dim3 grid(ch.count, split), block(64 * wpb);
             const int chunks = (ch.lmax + 63) / 64;
-            if (chunks <= 2) hipLaunchKernelGGL(k_invit_reg<2>, grid, block, 0, st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
-            else if (chunks <= 4) hipLaunchKernelGGL(k_invit_reg<4>, grid, block, 0, st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
-            else hipLaunchKernelGGL(k_invit_reg<8>, grid, block, 0, st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
+            // dynamic LDS: the multipliers of a solve, MAXC x 64 complex per wavefront
+            if (chunks <= 2) hipLaunchKernelGGL(k_invit_reg<2>, grid, block, wpb * 2 * 64 * sizeof(cd), st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
+            else if (chunks <= 4) hipLaunchKernelGGL(k_invit_reg<4>, grid, block, wpb * 4 * 64 * sizeof(cd), st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
+            else hipLaunchKernelGGL(k_invit_reg<8>, grid, block, wpb * 8 * 64 * sizeof(cd), st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
         } else
         hipLaunchKernelGGL(k_invit, dim3(ch.count, ctx->split_invit), dim3(ctx->nt_invit), sm, st, pl->d_items, perm,
                            pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm);

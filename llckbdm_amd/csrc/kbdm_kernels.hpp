@@ -935,8 +935,9 @@ __global__ void __launch_bounds__(512) k_invit_reg(const KbItem* __restrict__ it
     if (threadIdx.x == 0) weak = 0;
     __syncthreads();
     const int wpb = blockDim.x >> 6;
+    // dynamic LDS (kb_smem): wpb x MAXC x 64 multipliers
     invit_reg<MAXC>(ctx, n, Hw, n, mu_out + it.line_off, hnorm, X, n, (int)blockIdx.y * wpb + ctx.wave(),
-                    (int)gridDim.y * wpb, &weak);
+                    (int)gridDim.y * wpb, &weak, reinterpret_cast<cd*>(kb_smem) + (size_t)ctx.wave() * MAXC * 64);
     __syncthreads();
     if (threadIdx.x == 0 && weak) atomicOr(&status[item], KB_STAT_INVIT_WEAK);
 }
