@@ -116,13 +116,15 @@ struct Hqr2Lds {
     int* sinfo;
     cd* Hw;
     Refl3* logv;
+    cd* dmy;        // zero triples for the lanes without an element (branch-free chase passes): KB2_DMY elements
     int* flag;
 };
+constexpr int KB2_DMY = 192 + 64 + 2 * 65;     // 3 per lane (row operations) + lane + {0, WP, 2 WP} (column operations), WP <= 65
 KB_HD int hqr2_win_elems(int W) { return W * (W + 1); }
 KB_HD int hqr2_log_entries(int W) { return W * KB2_NBMAX; }
 KB_HD int hqr2_scratch_bytes(int W) {
     return (KB2_NSMAX * KB2_NSMAX + KB2_NSMAX) * (int)sizeof(cd) + 64 + hqr2_win_elems(W) * (int)sizeof(cd) +
-           hqr2_log_entries(W) * (int)sizeof(Refl3) + 64;
+           hqr2_log_entries(W) * (int)sizeof(Refl3) + KB2_DMY * (int)sizeof(cd) + 64;
 }
 template <class C>
 KB_HD Hqr2Lds hqr2_lds(const C& ctx, int W) {
@@ -133,6 +135,7 @@ KB_HD Hqr2Lds hqr2_lds(const C& ctx, int W) {
     L.flag = L.sinfo + 4;
     L.Hw = reinterpret_cast<cd*>(reinterpret_cast<char*>(L.sinfo) + 64);
     L.logv = reinterpret_cast<Refl3*>(L.Hw + hqr2_win_elems(W));
+    L.dmy = reinterpret_cast<cd*>(L.logv + hqr2_log_entries(W));
     return L;
 }
 
@@ -456,13 +459,13 @@ __device__ __forceinline__ cd half_bcast(cd v) {
     return mk(__hiloint2double(b, a), __hiloint2double(d, c));
 }
 
-template <int W>
-__device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, Refl3* logv, const cd* sh, cd* core, int l,
+template <int W, bool PROF>
+__device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, Refl3* logv, const cd* sh, cd* dmy, int l,
                                                      int i, int nb, int t0, int t1, int ws, int we, int bmin, MsStats* stats) {
     constexpr int WP = W + 1;
-    // phase timers of wavefront `pw` (KBDM_HQR_PROF=1 only): tload = phase 1, treplay = wait at barrier 1, tstore = phase 2
+    // phase timers of wavefront 0 (PROF, KBDM_HQR_PROF=1 only): tload = phase 1, treplay = wait at barrier 1, tstore = phase 2
     // column operations, ntiles = reflector generation; the rest of cyc_chase is the wait at barrier 2
-    const bool prof = stats != nullptr && ctx.tid() == 0;
+    const bool prof = PROF && stats != nullptr && ctx.tid() == 0;
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #define HW(i_, j_) Hw[((i_) - ws) + ((j_) - ws) * WP]
     const int wv = ctx.wave(), lane = ctx.lane();
@@ -474,11 +477,17 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
     const int b = bmin + bl;
     const int na = i - l + 1;
     const int cmax = (i < we - 1) ? i : we - 1;
+    // The row / column operations are BRANCH-FREE: a lane without an element triple (and the third element of a triple
+    // that ends at the block's last row / column) works on a zero triple of its own in `dmy` instead - a unitary
+    // reflector leaves zeros zero - so the passes need no exec-mask bookkeeping around their loads and stores
+    // (the loop is bound by instruction issue: ~550 wavefront instructions per SIMD and interval before this).
+    //   dmy[3 lane .. 3 lane + 2]: the row-operation triple;  dmy[192 + lane + {0, WP, 2 WP}]: the column-operation triple
+    cd* const dm1 = dmy + 3 * lane;
+    cd* const dm2 = dmy + 192 + lane;
     auto active = [&](int t) { const int d = t - 3 * b; return wv < 8 && b <= nb - 1 && d >= 0 && d <= na - 2; };
     cd r_tau = czero(), r_v2 = czero(), r_v3 = czero();     // the reflector of the current interval (plain registers:
                                                             // a struct here ends up in scratch memory)
     double beta = 0.0;
-    (void)core;
     auto refl_from_window = [&](int t) {
         const int p = l + t - 3 * b;
         const bool three = p + 2 <= i;
@@ -523,22 +532,20 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
         // ---- phase 1: rows p..p+2, columns p..min(i, we-1); column p-1 becomes (beta, 0, 0)
         if (near_w) {
             if (act && p > l && hl < 3 && (hl < 2 || three)) HW(p + hl, p - 1) = mk(hl == 0 ? beta : 0.0, 0.0);
-            if (act && p + hl <= cmax) {
-                cd* a = &HW(p, p + hl);
-                cd x0 = a[0], x1 = a[1], x2 = three ? a[2] : czero();
-                apply3v<0>(r_tau, r_v2, r_v3, x0, x1, x2);
-                a[0] = x0; a[1] = x1;
-                if (three) a[2] = x2;
-            }
+            const bool on = act && p + hl <= cmax;
+            cd* a = on ? &HW(p, p + hl) : dm1;
+            cd* a2 = (on && three) ? a + 2 : dm1 + 2;
+            cd x0 = a[0], x1 = a[1], x2 = *a2;
+            apply3v<0>(r_tau, r_v2, r_v3, x0, x1, x2);
+            a[0] = x0; a[1] = x1; *a2 = x2;
         } else if (__builtin_amdgcn_ballot_w64(act && p + 32 <= cmax) != 0) {
-            if (act && p + 32 + hl <= cmax) {
-                { const cd* e = reinterpret_cast<const cd*>(logv + (t - t0) * KB2_NBMAX + bl); r_tau = e[0]; r_v2 = e[1]; r_v3 = e[2]; }
-                cd* a = &HW(p, p + 32 + hl);
-                cd x0 = a[0], x1 = a[1], x2 = three ? a[2] : czero();
-                apply3v<0>(r_tau, r_v2, r_v3, x0, x1, x2);
-                a[0] = x0; a[1] = x1;
-                if (three) a[2] = x2;
-            }
+            { const cd* e = reinterpret_cast<const cd*>(logv + (t - t0) * KB2_NBMAX + bl); r_tau = e[0]; r_v2 = e[1]; r_v3 = e[2]; }
+            const bool on = act && p + 32 + hl <= cmax;
+            cd* a = on ? &HW(p, p + 32 + hl) : dm1;
+            cd* a2 = (on && three) ? a + 2 : dm1 + 2;
+            cd x0 = a[0], x1 = a[1], x2 = *a2;
+            apply3v<0>(r_tau, r_v2, r_v3, x0, x1, x2);
+            a[0] = x0; a[1] = x1; *a2 = x2;
         }
         if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c1 = KB_CLOCK(); }
         ctx.sync();
@@ -549,24 +556,22 @@ __device__ __forceinline__ void chase2_intervals_dev(const DevCtx& ctx, cd* Hw, 
             const int rmax = (p + 3 < i) ? p + 3 : i;
             if (near_w) {
                 const int r = p - 28 + hl;                // rows p-28 .. p+3; lanes 29..31 are rows p+1..p+3
-                if (act && r >= ws && r <= rmax) {
-                    cd* a = &HW(r, p);
-                    cd y0 = a[0], y1 = a[WP], y2 = three ? a[2 * WP] : czero();
-                    apply3v<1>(r_tau, r_v2, r_v3, y0, y1, y2);
-                    a[0] = y0; a[WP] = y1;
-                    if (three) a[2 * WP] = y2;
-                    ynew = y0;
-                }
+                const bool on = act && r >= ws && r <= rmax;
+                cd* a = on ? &HW(r, p) : dm2;
+                cd* a2 = (on && three) ? a + 2 * WP : dm2 + 2 * WP;
+                cd y0 = a[0], y1 = a[WP], y2 = *a2;
+                apply3v<1>(r_tau, r_v2, r_v3, y0, y1, y2);
+                a[0] = y0; a[WP] = y1; *a2 = y2;
+                ynew = y0;                                // (zero on a lane without a row)
             } else if (__builtin_amdgcn_ballot_w64(act && p - 29 >= ws) != 0) {
                 const int r = p - 60 + hl;                // rows p-60 .. p-29
-                if (act && r >= ws) {
-                    { const cd* e = reinterpret_cast<const cd*>(logv + (t - t0) * KB2_NBMAX + bl); r_tau = e[0]; r_v2 = e[1]; r_v3 = e[2]; }
-                    cd* a = &HW(r, p);
-                    cd y0 = a[0], y1 = a[WP], y2 = three ? a[2 * WP] : czero();
-                    apply3v<1>(r_tau, r_v2, r_v3, y0, y1, y2);
-                    a[0] = y0; a[WP] = y1;
-                    if (three) a[2 * WP] = y2;
-                }
+                { const cd* e = reinterpret_cast<const cd*>(logv + (t - t0) * KB2_NBMAX + bl); r_tau = e[0]; r_v2 = e[1]; r_v3 = e[2]; }
+                const bool on = act && r >= ws;
+                cd* a = on ? &HW(r, p) : dm2;
+                cd* a2 = (on && three) ? a + 2 * WP : dm2 + 2 * WP;
+                cd y0 = a[0], y1 = a[WP], y2 = *a2;
+                apply3v<1>(r_tau, r_v2, r_v3, y0, y1, y2);
+                a[0] = y0; a[WP] = y1; *a2 = y2;
             }
         }
         if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = KB_CLOCK(); }
@@ -669,8 +674,13 @@ KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, con
         const long long c_b = KB_CLOCK();
         // ---- (b) chase inside the window, logging the reflectors
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (W == 56) chase2_intervals_dev<56>(ctx, Hw, logv, sh, L.S, l, i, nb, t0, t1, ws, we, bmin, stats);
-        else chase2_intervals_dev<64>(ctx, Hw, logv, sh, L.S, l, i, nb, t0, t1, ws, we, bmin, stats);
+        if (stats) {
+            if (W == 56) chase2_intervals_dev<56, true>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, stats);
+            else chase2_intervals_dev<64, true>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, stats);
+        } else {
+            if (W == 56) chase2_intervals_dev<56, false>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, nullptr);
+            else chase2_intervals_dev<64, false>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, nullptr);
+        }
 #else
         const int cmax = (i < we - 1) ? i : we - 1;
         for (int t = t0; t < t1; ++t) {
@@ -1003,6 +1013,7 @@ KB_HD void hqr2_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info, in
     cd* aws = L.Hw;                                   // Aberth workspace: the window image, idle between chases
     int fail = 0;
     bool bail = false;
+    for (int idx = tid; idx < KB2_DMY; idx += nt) L.dmy[idx] = czero();   // the chase's zero triples (device passes)
     if (n == 1) {
         if (tid == 0) { w[0] = HH(0, 0); *info = 0; }
         ctx.sync();

