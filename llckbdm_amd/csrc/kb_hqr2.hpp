@@ -23,6 +23,7 @@ namespace kb {
 
 constexpr int KB2_NBMAX = 8;        // bulges in flight (2 shifts each)
 constexpr int KB2_NSMAX = 16;       // shifts per sweep
+constexpr int KB2_WIN_DEV = 56;     // LDS window of the device kernels (W = 64 measured 3 % faster on one member but is not validated)
 constexpr int KB2_MS_MIN = 9;       // below this active size: single-shift sweeps (blocks of at most 8: every
                                     // element they touch is within 7 of the diagonal, i.e. inside the chase
                                     // workgroup's windows and its one top unit)
@@ -674,13 +675,10 @@ KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, con
         const long long c_b = KB_CLOCK();
         // ---- (b) chase inside the window, logging the reflectors
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (stats) {
-            if (W == 56) chase2_intervals_dev<56, true>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, stats);
-            else chase2_intervals_dev<64, true>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, stats);
-        } else {
-            if (W == 56) chase2_intervals_dev<56, false>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, nullptr);
-            else chase2_intervals_dev<64, false>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, nullptr);
-        }
+        // the device chase is compiled for W = KB2_WIN_DEV (window addresses are lane-constant plus compile-time offsets);
+        // the host library passes exactly this window (the generic code around it, and the host simulation, take any W)
+        if (stats) chase2_intervals_dev<KB2_WIN_DEV, true>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, stats);
+        else chase2_intervals_dev<KB2_WIN_DEV, false>(ctx, Hw, logv, sh, L.dmy, l, i, nb, t0, t1, ws, we, bmin, nullptr);
 #else
         const int cmax = (i < we - 1) ? i : we - 1;
         for (int t = t0; t < t1; ++t) {

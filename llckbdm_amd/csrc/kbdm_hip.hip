@@ -113,7 +113,7 @@ struct kbdm_ctx {
     int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
     int hqr_v = 2;        // QR iteration: 2 = kb_hqr2.hpp (double-shift bulges, systolic strips), 1 = round-1 kernels
     int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
-    int win_hqr2 = 56;    // its LDS window
+    int win_hqr2 = KB2_WIN_DEV;   // its LDS window (fixed: the device chase is compiled for it)
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
     // multi-GPU: RCCL communicator (one per context) and the device buffers of the packed gather
@@ -696,7 +696,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
     c->stream_wpb = env_int("KBDM_STREAM_WPB", c->stream_wpb);
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
-    c->win_hqr2 = std::min(64, std::max(3 * c->nb_hqr2 + 8, env_int("KBDM_WIN_HQR2", c->win_hqr2)));
+    c->win_hqr2 = KB2_WIN_DEV;                       // the device chase is compiled for this window
     if (c->ns_hqr > KB_MS_NSMAX) c->ns_hqr = KB_MS_NSMAX;
     if (c->win_hqr > 0 && c->win_hqr < 3 * c->ns_hqr + 8) c->win_hqr = 3 * c->ns_hqr + 8;
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
