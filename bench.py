@@ -389,7 +389,7 @@ def main():
         achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
         # the kernel behind the dominant stage timer (lane 0 runs the QR iteration as the team kernel)
         hqr_v2 = os.environ.get("KBDM_HQR_V", "2") != "1"
-        kname = {"k_hqr": "k_hqr2_team" if hqr_v2 else "k_hqr_team", "k_svd_fac": "k_bidiag_panel", "k_hess": "k_hess_panel",
+        kname = {"k_hqr": "k_hqr2_team" if hqr_v2 else "k_hqr_team", "k_svd_fac": "k_bidiag_panel<0>", "k_hess": "k_hess_panel",
                  "k_gen(Q,P)": "k_gen<8>", "k_bdsqr_apply": "k_bdsqr_stream", "k_invit": "k_invit_reg<8>"}.get(dom, dom)
         # HBM bytes per launch of that kernel: NOT measured by this run - taken from the newest committed PMC passes
         # (profiles/*_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command), if any

@@ -70,7 +70,7 @@ KB_HD cd hess_vt(const cd* W, int ld, int p0, int r, int t) {
 }
 KB_HD int hess_panel_scratch_bytes(int n, int nwaves, int ws) {
     int z = n > nwaves * ws ? n : nwaves * ws;
-    return (n + z + 2 * KB_NB + KB_NB * KB_NB + 8) * (int)sizeof(cd);
+    return (n + z + 4 * n + 2 * KB_NB + KB_NB * KB_NB + 8) * (int)sizeof(cd);
 }
 
 template <class C>
@@ -83,20 +83,19 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
     cd* ub = reinterpret_cast<cd*>(ctx.scratch());           // v (indexed by global row)
     cd* zp = ub + N;
     const int zcap = N > ctx.nwaves() * C::WS ? N : ctx.nwaves() * C::WS;
-    cd* w1 = zp + zcap;                                      // V^H v  /  V^H x
+    cd* sp = zp + zcap;                                      // partial sums of the "skinny" sweeps: 4 N entries
+    cd* w1 = sp + 4 * N;                                     // V^H v  /  V^H x
     cd* w2 = w1 + KB_NB;                                     // T^H (V^H x)
     cd* Tm = w2 + KB_NB;                                     // T, NB x NB upper triangular
+    // sweeps with fewer rows than threads: two thread groups split the columns t so far (see bidiag_panel)
+    const int G = (2 * N <= nt) ? 2 : 1;
+    const int gsz = nt / G;
+    const int g = tid / gsz, gi = tid - g * gsz;
     for (int idx = tid; idx < KB_NB * KB_NB; idx += nt) Tm[idx] = czero();
     ctx.sync();
     for (int j = 0; j < KB_NB; ++j) {
         const int k = p0 + j;
-        // ---- 1a. x = A0(:, k) - Y_j V_j(k, :)^H, all rows
-        for (int r = tid; r < N; r += nt) {
-            cd acc = W_(r, k);
-            for (int t = 0; t < j; ++t) acc = acc - Y_(r, t) * conj(hess_vt(W, ld, p0, k, t));
-            W_(r, k) = acc;
-        }
-        ctx.sync();
+        // ---- 1a. x = A0(:, k) - Y_j V_j(k, :)^H, all rows: formed by the last sweep of column j - 1 (step 4 below)
         if (j > 0) {
             // ---- 1b. w1 = V_j^H x (one wavefront per dot product), w2 = T_j^H w1, x -= V_j w2
             for (int t = ctx.wave(); t < j; t += ctx.nwaves()) {
@@ -112,10 +111,16 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
                 w2[t] = acc;
             }
             ctx.sync();
+            for (int r = p0 + 1 + gi; r < N; r += gsz) {
+                cd acc = czero();
+                for (int t = g; t < j; t += G) acc = acc + hess_vt(W, ld, p0, r, t) * w2[t];
+                sp[g * N + r] = acc;
+            }
+            ctx.sync();
             for (int r = p0 + 1 + tid; r < N; r += nt) {
-                cd acc = W_(r, k);
-                for (int t = 0; t < j; ++t) acc = acc - hess_vt(W, ld, p0, r, t) * w2[t];
-                W_(r, k) = acc;
+                cd acc = sp[r];
+                if (G == 2) acc = acc + sp[N + r];
+                W_(r, k) = W_(r, k) - acc;
             }
             ctx.sync();
         }
@@ -127,15 +132,14 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
         for (int r = k + 1 + tid; r < N; r += nt) ub[r] = (r == k + 1) ? mk(1.0, 0.0) : W_(r, k);
         ctx.sync();
         if (tid == 0) { tauh[j] = tau; W_(k + 1, k) = mk(beta, 0.0); }
-        // ---- 3. w1 = V_j^H v
+        // ---- 3. w1 = V_j^H v  and, in the same phase,
+        // ---- 4. y = tau (A0[:, k+1:] v - Y_j w1), all rows: the one pass over A0 of this column
         for (int t = ctx.wave(); t < j; t += ctx.nwaves()) {
             cd acc = czero();
             for (int r = k + 1 + lane; r < N; r += C::WS) cfmac(acc, hess_vt(W, ld, p0, r, t), ub[r]);
             acc = ctx.wave_sum(acc);
             if (lane == 0) w1[t] = acc;
         }
-        ctx.sync();
-        // ---- 4. y = tau (A0[:, k+1:] v - Y_j w1), all rows: the one pass over A0 of this column
         {
             const int ncols = N - k - 1;
             const int nw = ctx.nwaves();
@@ -160,11 +164,28 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
                 }
             }
             ctx.sync();
+            // the corrections of y with Y_j w1 and - same rows, same columns of Y - column k + 1 of A0 - Y_{j+1} V_{j+1}(k+1, :)^H
+            // for the next step (one sweep instead of two)
+            const bool nextcol = j + 1 < KB_NB;
+            for (int r = gi; r < N; r += gsz) {
+                cd hp = czero(), np = czero();
+                for (int t = g; t < j; t += G) {
+                    const cd yrt = Y_(r, t);
+                    hp = hp + yrt * w1[t];
+                    if (nextcol) np = np + yrt * conj(hess_vt(W, ld, p0, k + 1, t));
+                }
+                sp[(0 * G + g) * N + r] = hp;
+                sp[(1 * G + g) * N + r] = np;
+            }
+            ctx.sync();
             for (int r = tid; r < N; r += nt) {
                 cd h = czero();
-                for (int g = 0; g < ncg; ++g) h += zp[g * N + r];
-                for (int t = 0; t < j; ++t) h = h - Y_(r, t) * w1[t];
-                Y_(r, j) = tau * h;
+                for (int gz = 0; gz < ncg; ++gz) h += zp[gz * N + r];
+                cd hp = sp[r], np = sp[G * N + r];
+                if (G == 2) { hp = hp + sp[N + r]; np = np + sp[3 * N + r]; }
+                const cd y = tau * (h - hp);
+                Y_(r, j) = y;
+                if (nextcol) W_(r, k + 1) = (W_(r, k + 1) - np) - y;            // ... - Y(r, j) conj(V(k+1, j)), V(k+1, j) = 1
             }
         }
         // ---- 5. T(0:j, j) = -tau T_j w1, T(j, j) = tau
@@ -179,20 +200,48 @@ KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* 
         ctx.sync();
     }
     // ---- VT = V T (all rows; rows <= p0 are zero) and MT = (Y^H V) T for the deferred left factor
-    for (int r = tid; r < N; r += nt)
-        for (int t = 0; t < KB_NB; ++t) {
-            cd acc = czero();
-            for (int s2 = 0; s2 <= t; ++s2) cfma(acc, hess_vt(W, ld, p0, r, s2), T_(s2, t));
-            VT[r + (size_t)t * ldvt] = acc;
+    for (int idx = tid; idx < N * 2; idx += nt) {             // two threads per row: the even / the odd columns t
+        const int r = idx >> 1, half = idx & 1;
+        cd acc[KB_NB / 2];
+#pragma unroll
+        for (int q = 0; q < KB_NB / 2; ++q) acc[q] = czero();
+        for (int s2 = 0; s2 < KB_NB; ++s2) {                  // T is upper triangular with explicit zeros below
+            const cd v = hess_vt(W, ld, p0, r, s2);
+#pragma unroll
+            for (int q = 0; q < KB_NB / 2; ++q) cfma(acc[q], v, T_(s2, 2 * q + half));
         }
+#pragma unroll
+        for (int q = 0; q < KB_NB / 2; ++q) VT[r + (size_t)(2 * q + half) * ldvt] = acc[q];
+    }
     ctx.sync();
-    // (Y^H V T)(u, t) = sum_r conj(Y(r,u)) VT(r,t): one wavefront per entry
-    for (int e = ctx.wave(); e < KB_NB * KB_NB; e += ctx.nwaves()) {
-        const int u = e % KB_NB, t = e / KB_NB;
+    // (Y^H V T)(u, t) = sum_r conj(Y(r,u)) VT(r,t): one thread per entry, the rows staged through LDS in slabs
+    // (sp: 4 N entries = slabs of 2 N / NB rows of Y and of VT)
+    {
+        const int slab = (2 * N / KB_NB) < 1 ? 1 : (2 * N / KB_NB);     // rows per slab: slab * NB entries each for Y and VT
+        cd* sy = sp;
+        cd* sv = sp + (size_t)slab * KB_NB;
+        const int u = tid % KB_NB, t = tid / KB_NB;                     // entry of this thread (tid < NB * NB)
         cd acc = czero();
-        for (int r = p0 + 1 + lane; r < N; r += C::WS) cfmac(acc, Y_(r, u), VT[r + (size_t)t * ldvt]);
-        acc = ctx.wave_sum(acc);
-        if (lane == 0) MT[u + t * KB_NB] = acc;
+        for (int r0 = p0 + 1; r0 < N; r0 += slab) {
+            const int rows = (N - r0 < slab) ? N - r0 : slab;
+            for (int idx = tid; idx < rows * KB_NB; idx += nt) {
+                const int rr = idx % rows, cc = idx / rows;
+                sy[rr + cc * slab] = Y_(r0 + rr, cc);
+                sv[rr + cc * slab] = VT[(r0 + rr) + (size_t)cc * ldvt];
+            }
+            ctx.sync();
+            if (tid < KB_NB * KB_NB)
+                for (int rr = 0; rr < rows; ++rr) cfmac(acc, sy[rr + u * slab], sv[rr + t * slab]);
+            ctx.sync();
+        }
+        if (tid < KB_NB * KB_NB) MT[u + t * KB_NB] = acc;
+        // (fewer threads than entries - the host simulation - : the remaining entries)
+        for (int e = tid + nt; e < KB_NB * KB_NB; e += nt) {
+            const int uu = e % KB_NB, tt = e / KB_NB;
+            cd a2 = czero();
+            for (int r = p0 + 1; r < N; ++r) cfmac(a2, Y_(r, uu), VT[r + (size_t)tt * ldvt]);
+            MT[uu + tt * KB_NB] = a2;
+        }
     }
     ctx.sync();
 #undef W_
