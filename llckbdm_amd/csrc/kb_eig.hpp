@@ -709,10 +709,16 @@ __device__ __forceinline__ cd kb_bcast(cd v, int l) {
 // full, where the diagonal / the new y / the multiplier go), so the vector part of a chunk is eight FMAs.
 __device__ __forceinline__ cd csel2(bool c, cd a, cd b) { return mk(c ? a.x : b.x, c ? a.y : b.y); }
 
-template <int MAXC>
+// STREAM (members of more than 512 rows): the raw column is not double-buffered in registers - only the chunk that holds
+// the pivot row is fetched one step ahead (nxt[0]), the others are loaded where they are used - and the multipliers go to
+// global memory (the output column of this eigenvalue, free until the solve is over) instead of LDS: 2 x MAXC chunks of
+// registers instead of 4, so that 20 chunks (1280 rows) fit.
+constexpr int KB_INVIT_BIG_MAXC = 20;     // register chunks of the streaming form: members of up to 1280 rows
+
+template <int MAXC, bool STREAM = false>
 struct InvitRegState {
-    cd cand[MAXC], bv[MAXC], nxt[MAXC];
-    cd* fmL;                                                  // multipliers f_j of this solve: LDS, MAXC * 64 entries per wavefront
+    cd cand[MAXC], bv[MAXC], nxt[STREAM ? 1 : MAXC];
+    cd* fmL;                                                  // multipliers f_j of this solve: LDS, MAXC * 64 entries per wavefront (STREAM: global)
     unsigned swp;
     bool rescaled;
     cd wk;
@@ -727,14 +733,27 @@ struct InvitRegState {
         const int lp = LP0 ? 0 : p - 64 * CJ;                 // lane of row p (chunk CJ)
         const int lj = LP0 ? 63 : lp - 1;                     // lane of row j (chunk CK)
         cd cur[MAXC];
+        if constexpr (!STREAM) {
 #pragma unroll
-        for (int c = 0; c <= CJ; ++c) cur[c] = nxt[c];
-        if (j >= 1) {                                          // raw column j - 1, rows <= j, for the next step
-            const cd* __restrict__ Hc = H + (size_t)(j - 1) * ldh + lane;
+            for (int c = 0; c <= CJ; ++c) cur[c] = nxt[c];
+            if (j >= 1) {                                      // raw column j - 1, rows <= j, for the next step
+                const cd* __restrict__ Hc = H + (size_t)(j - 1) * ldh + lane;
 #pragma unroll
-            for (int c = 0; c < CK; ++c) nxt[c] = Hc[64 * c];
-            nxt[CK] = (LP0 || lane <= lj) ? Hc[64 * CK] : czero();
+                for (int c = 0; c < CK; ++c) nxt[c] = Hc[64 * c];
+                nxt[CK] = (LP0 || lane <= lj) ? Hc[64 * CK] : czero();
+            }
+        } else {
+            cur[CJ] = nxt[0];                                  // the chunk of row p, fetched during the step before
+            if (j >= 1) {                                      // ... and the one of row p - 1 of column j - 1 for the next step
+                constexpr int CN = LP0 ? CJ - 1 : CJ;
+                nxt[0] = (lane + 64 * CN <= p - 1) ? H[(size_t)(j - 1) * ldh + lane + 64 * CN] : czero();
+            }
+            if constexpr (LP0) cur[CK] = H[(size_t)j * ldh + lane + 64 * CK];     // (row j sits in the chunk below)
         }
+        // STREAM: the chunks below CK are loaded where they are used, four at a time (a compiler barrier keeps the loads of
+        // the next group from being hoisted: with all of a column in flight the allocation spills)
+        const cd* __restrict__ Hj = H + (size_t)j * ldh + lane;
+        (void)Hj;
         const cd rsub = kb_bcast(cur[CJ], lp);                // B(j+1, j) = H(j+1, j)
         cd cpiv = kb_bcast(cand[CJ], lp);                     // diagonal of the candidate
         const cd bp = kb_bcast(bv[CJ], lp);
@@ -756,7 +775,42 @@ struct InvitRegState {
             cur[CK] = mk(dj ? cur[CK].x - wk.x : cur[CK].x, dj ? cur[CK].y - wk.y : cur[CK].y);
         }
         const bool top = LP0 || lane <= lj;                    // rows <= j of chunk CK
-        if (swap) {                                            // the raw column is final at position j + 1
+        if constexpr (STREAM) {
+            // the chunks below CK in groups of four: the group's loads, then ONE scalar branch on the pivot choice.  The
+            // compiler barrier in front of every group keeps later groups' loads (which both sides of the branch share, so
+            // that they would be hoisted above it) from being issued early: with a whole column in flight the allocation
+            // spills by the kilobyte.
+#pragma unroll
+            for (int c0 = 0; c0 < CK; c0 += 4) {
+                asm volatile("" ::: "memory");
+                cd raw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + q < CK) raw[q] = Hj[64 * (c0 + q)];
+                if (swap) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < CK) {
+                            cand[c0 + q] = cand[c0 + q] - f * raw[q];
+                            bv[c0 + q] = bv[c0 + q] - yj1 * raw[q];
+                        }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < CK) {
+                            const cd cn = cand[c0 + q];
+                            cand[c0 + q] = raw[q] - f * cn;
+                            bv[c0 + q] = bv[c0 + q] - yj1 * cn;
+                        }
+                }
+            }
+            asm volatile("" ::: "memory");
+            const cd raw = cur[CK], cn = cand[CK];
+            const cd nc = swap ? cn - f * raw : raw - f * cn;
+            const cd nb = bv[CK] - yj1 * (swap ? raw : cn);
+            cand[CK] = csel2(top, nc, cn);
+            bv[CK] = csel2(top, nb, bv[CK]);
+        } else if (swap) {                                     // the raw column is final at position j + 1
 #pragma unroll
             for (int c = 0; c < CK; ++c) {
                 const cd raw = cur[c];
@@ -792,6 +846,10 @@ struct InvitRegState {
     // all positions of chunk CJ, top down
     template <int CJ>
     __device__ __forceinline__ void chunk(int n) {
+        if constexpr (STREAM) {
+            // the first chunk of the solve: fetch the pivot-row chunk of column n - 2 (rows <= n - 1)
+            if (n - 1 < 64 * (CJ + 1)) nxt[0] = (n >= 2 && lane + 64 * CJ <= n - 1) ? H[(size_t)(n - 2) * ldh + lane + 64 * CJ] : czero();
+        }
         const int phi = (n - 1 < 64 * CJ + 63) ? n - 1 : 64 * CJ + 63;
         const int plo = 64 * CJ + 1;                           // lp >= 1
         for (int p = phi; p >= plo; --p) step<CJ, false>(p);
@@ -801,13 +859,13 @@ struct InvitRegState {
     }
 };
 
-template <int MAXC, int CJ>
-__device__ __forceinline__ void invit_chunks(InvitRegState<MAXC>& S, int n) {
+template <int MAXC, bool STREAM, int CJ>
+__device__ __forceinline__ void invit_chunks(InvitRegState<MAXC, STREAM>& S, int n) {
     if (n - 1 >= 64 * CJ) S.template chunk<CJ>(n);
-    if constexpr (CJ >= 1) invit_chunks<MAXC, CJ - 1>(S, n);
+    if constexpr (CJ >= 1) invit_chunks<MAXC, STREAM, CJ - 1>(S, n);
 }
 
-template <int MAXC>
+template <int MAXC, bool STREAM = false>
 __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, int ldh, const cd* __restrict__ w,
                           double hnorm, cd* __restrict__ X, int ldx, int kk_begin, int kk_step, int* weak, cd* fmL) {
     const int lane = ctx.lane();
@@ -823,7 +881,8 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
             cnt = (int)ctx.wave_sum((double)cnt);
             wk.x += cnt * eps3;
         }
-        InvitRegState<MAXC> S;
+        InvitRegState<MAXC, STREAM> S;
+        if (STREAM) fmL = X + (size_t)kk * ldx;          // the multipliers borrow the output column
         cd (&cand)[MAXC] = S.cand;
         cd (&bv)[MAXC] = S.bv;
         unsigned& swp = S.swp;             // bit c: swap flag of element lane + 64 c
@@ -847,13 +906,15 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
             }
             swp = 0;
             S.rescaled = false;
+            if constexpr (!STREAM) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int r = lane + 64 * c;
-                S.nxt[c] = (n >= 2 && r <= n - 1) ? H[r + (size_t)(n - 2) * ldh] : czero();
+                for (int c = 0; c < MAXC; ++c) {
+                    const int r = lane + 64 * c;
+                    S.nxt[c] = (n >= 2 && r <= n - 1) ? H[r + (size_t)(n - 2) * ldh] : czero();
+                }
             }
             // position p = j + 1 runs from n-1 down to 1; the chunk of p is a compile-time index
-            invit_chunks<MAXC, MAXC - 1>(S, n);
+            invit_chunks<MAXC, STREAM, MAXC - 1>(S, n);
             const bool rescaled = S.rescaled;
             {
                 cd p0 = kb_bcast(cand[0], 0);
@@ -864,9 +925,11 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
 #pragma unroll
                 for (int cj = 0; cj < MAXC; ++cj) {
                     const int jhi = (n - 2 < 64 * cj + 63) ? n - 2 : 64 * cj + 63;
+                    cd fch = czero();                              // STREAM: this chunk of the multipliers, one coalesced load
+                    if (STREAM && 64 * cj <= jhi) fch = (lane + 64 * cj <= jhi) ? fmL[lane + 64 * cj] : czero();
                     for (int j = 64 * cj; j <= jhi; ++j) {
                         const int lj = j - 64 * cj;
-                        const cd f = fmL[j];
+                        const cd f = STREAM ? kb_bcast(fch, lj) : fmL[j];
                         const bool sw = (__builtin_amdgcn_readlane((int)swp, lj) >> cj) & 1;
                         cd b;
                         if (lj < 63) b = kb_bcast(bv[cj], lj + 1);

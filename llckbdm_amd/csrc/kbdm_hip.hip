@@ -569,7 +569,15 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (nw < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
         const int sm = KB_RED_BYTES + nw * per;
         HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // eigenvalues of the solo members (side stream) and Qh
-        if (ctx->invit_reg && ch.lmax <= 512) {
+        if (ctx->invit_reg && ch.lmax > 512 && ch.lmax <= KB_INVIT_BIG_MAXC * 64) {
+            // register-resident solves for members of up to 1280 rows (streaming form, no LDS); four wavefronts per
+            // workgroup = one per SIMD: a wavefront may then use accumulation registers next to its 256 VGPRs
+            const int wpb = 4;
+            int split = (ch.lmax + 2 * wpb - 1) / (2 * wpb);
+            split = std::max(1, std::min(split, 64));
+            hipLaunchKernelGGL(k_invit_big<KB_INVIT_BIG_MAXC>, dim3(ch.count, split), dim3(64 * wpb), 0, st, pl->d_items, perm, pl->d_arena,
+                               pl->d_varena, pl->d_mu, pl->d_status);
+        } else if (ctx->invit_reg && ch.lmax <= 512) {
             // register-resident solves: no LDS; enough wavefronts that every one solves about two eigenvalues
             const int wpb = 8;
             int split = (ch.lmax + 2 * wpb - 1) / (2 * wpb);

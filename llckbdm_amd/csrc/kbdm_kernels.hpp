@@ -122,34 +122,38 @@ constexpr int KB_TU_PITCH = 80;   // doubles per k row in LDS
 
 // `nch` = number of 8-deep k chunks (a runtime value: the blocked reductions use 2 NB / 8, the compact-WY generation of
 // the unitary factors uses the panel height / 8 and NB / 8); STORE = false: C -= product, true: C = product.
-template <bool STORE, class FA, class FB, class FC>
-__device__ __forceinline__ void mfma_tile_k(FA Aop, FB Bop, FC Cptr, int NCH) {
+// KFAST: the operands are read k-fastest (thread t stages k = t & 7 of rows t >> 3 and (t >> 3) + 32): for products whose
+// operands are contiguous along k in memory (A^H B: both factors column-major with k = the row index).
+template <bool STORE, bool KFAST, class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_tile_kx(FA Aop, FB Bop, FC Cptr, int NCH) {
     __shared__ double s_op[2][2][2][KB_TU_KC][KB_TU_PITCH];   // [buffer][A|B][re|im][k][row]
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
-    const int srow = t & 63, sk = t >> 6;                       // staging: row, k (and k + 4)
+    // staging: thread t holds (row srow, k = sk) and (row srow + srow2, k = sk + sk2) of a chunk
+    const int srow = KFAST ? (t >> 3) : (t & 63), sk = KFAST ? (t & 7) : (t >> 6);
+    constexpr int srow2 = KFAST ? 32 : 0, sk2 = KFAST ? 0 : 4;
     kb_d4 acc_re[2][2], acc_im[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
     cd ga[2], gb[2];
-    ga[0] = Aop(srow, sk); ga[1] = Aop(srow, sk + 4);
-    gb[0] = Bop(srow, sk); gb[1] = Bop(srow, sk + 4);
+    ga[0] = Aop(srow, sk); ga[1] = Aop(srow + srow2, sk + sk2);
+    gb[0] = Bop(srow, sk); gb[1] = Bop(srow + srow2, sk + sk2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        s_op[0][0][0][sk + 4 * j][srow] = ga[j].x; s_op[0][0][1][sk + 4 * j][srow] = ga[j].y;
-        s_op[0][1][0][sk + 4 * j][srow] = gb[j].x; s_op[0][1][1][sk + 4 * j][srow] = gb[j].y;
+        s_op[0][0][0][sk + sk2 * j][srow + srow2 * j] = ga[j].x; s_op[0][0][1][sk + sk2 * j][srow + srow2 * j] = ga[j].y;
+        s_op[0][1][0][sk + sk2 * j][srow + srow2 * j] = gb[j].x; s_op[0][1][1][sk + sk2 * j][srow + srow2 * j] = gb[j].y;
     }
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < NCH) {
             const int kn = (ch + 1) * KB_TU_KC + sk;
-            ga[0] = Aop(srow, kn); ga[1] = Aop(srow, kn + 4);
-            gb[0] = Bop(srow, kn); gb[1] = Bop(srow, kn + 4);
+            ga[0] = Aop(srow, kn); ga[1] = Aop(srow + srow2, kn + sk2);
+            gb[0] = Bop(srow, kn); gb[1] = Bop(srow + srow2, kn + sk2);
         }
 #pragma unroll
         for (int ks = 0; ks < KB_TU_KC; ks += 4) {
@@ -175,8 +179,8 @@ __device__ __forceinline__ void mfma_tile_k(FA Aop, FB Bop, FC Cptr, int NCH) {
         if (ch + 1 < NCH) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                s_op[buf ^ 1][0][0][sk + 4 * j][srow] = ga[j].x; s_op[buf ^ 1][0][1][sk + 4 * j][srow] = ga[j].y;
-                s_op[buf ^ 1][1][0][sk + 4 * j][srow] = gb[j].x; s_op[buf ^ 1][1][1][sk + 4 * j][srow] = gb[j].y;
+                s_op[buf ^ 1][0][0][sk + sk2 * j][srow + srow2 * j] = ga[j].x; s_op[buf ^ 1][0][1][sk + sk2 * j][srow + srow2 * j] = ga[j].y;
+                s_op[buf ^ 1][1][0][sk + sk2 * j][srow + srow2 * j] = gb[j].x; s_op[buf ^ 1][1][1][sk + sk2 * j][srow + srow2 * j] = gb[j].y;
             }
         }
         __syncthreads();
@@ -200,6 +204,11 @@ __device__ __forceinline__ void mfma_tile_k(FA Aop, FB Bop, FC Cptr, int NCH) {
                     }
                 }
             }
+}
+
+template <bool STORE, class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_tile_k(FA Aop, FB Bop, FC Cptr, int NCH) {
+    mfma_tile_kx<STORE, false>(Aop, Bop, Cptr, NCH);
 }
 template <class FA, class FB, class FC>
 __device__ __forceinline__ void mfma_rank2nb_tile(FA Aop, FB Bop, FC Cptr) {
@@ -689,48 +698,29 @@ __global__ void __launch_bounds__(256) k_hess_z(const KbItem* __restrict__ items
     cd* Z = arena + it.off[KB_BUF_H];
     const cd* MT = Z + (size_t)n * KB_NB;
     const cd* VT = MT + KB_NB * KB_NB;
-    constexpr int RC = 16;
-    __shared__ cd sA[RC][64 + 1];
-    __shared__ cd sV[RC][KB_NB];
-    const int t = threadIdx.x;
-    const int cl = t & 63, tg = t >> 6;               // column of this thread, group of 8 outputs (uniform per wavefront)
-    cd acc[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = czero();
-    for (int r0 = p0 + 1; r0 < n; r0 += RC) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = t + 256 * i;
-            const int rr = e & (RC - 1), cc = e >> 4;
-            const int r = r0 + rr, c = c0 + cc;
-            sA[rr][cc] = (r < n && c < n) ? W[r + (size_t)c * n] : czero();
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = t + 256 * i;
-            const int rr = e & (RC - 1), tt = e >> 4;
-            const int r = r0 + rr;
-            sV[rr][tt] = (r < n) ? VT[r + (size_t)tt * n] : czero();
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rr = 0; rr < RC; ++rr) {
-            const cd a = sA[rr][cl];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) cfmac(acc[o], a, sV[rr][tg * 8 + o]);
-        }
-        __syncthreads();
-    }
-    const int c = c0 + cl;
-    if (c < n) {
-        for (int u = 0; u < KB_NB; ++u) {
-            const cd v = hess_vt(W, n, p0, c, u);           // V(c, u) (the head of the last reflector sits at c = cbase)
-#pragma unroll
-            for (int o = 0; o < 8; ++o) acc[o] = acc[o] - v * MT[u + (tg * 8 + o) * KB_NB];
-        }
-#pragma unroll
-        for (int o = 0; o < 8; ++o) Z[c + (size_t)(tg * 8 + o) * n] = acc[o];
-    }
+    // Z[c, t] = sum_r conj(A0[r, c]) VT[r, t] - sum_u V(c, u) MT[u, t]  as ONE FP64-MFMA tile product over k = (the rows
+    // r = p0 + 1 .. n - 1, padded to a multiple of 8) ++ (u = 0 .. NB - 1):  Aop(c, k) = conj(A0[r, c]) | -V(c, u),
+    // Bop(t, k) = conj(VT[r, t]) | conj(MT[u, t])  (the tile computes sum_k Aop conj(Bop)); both operands are contiguous
+    // along r: k-fastest staging.  Only 32 of the tile's 64 columns exist (t < NB): half the MFMAs multiply zeros, still
+    // several times the rate of the vector-FMA tiles this replaces (3.3 TFLOP/s on the C4 batch).
+    const int K1 = n - p0 - 1, K1p = (K1 + KB_TU_KC - 1) / KB_TU_KC * KB_TU_KC;
+    mfma_tile_kx<true, true>(
+        [&](int i, int k) -> cd {
+            const int c = c0 + i;
+            if (c >= n) return czero();
+            if (k < K1p) { const int r = p0 + 1 + k; return (r < n) ? conj(W[r + (size_t)c * n]) : czero(); }
+            return -hess_vt(W, n, p0, c, k - K1p);           // V(c, u) (the head of the last reflector sits at c = cbase)
+        },
+        [&](int i, int k) -> cd {
+            if (i >= KB_NB) return czero();
+            if (k < K1p) { const int r = p0 + 1 + k; return (r < n) ? conj(VT[r + (size_t)i * n]) : czero(); }
+            return conj(MT[(k - K1p) + i * KB_NB]);
+        },
+        [&](int i, int jx) -> cd* {
+            const int c = c0 + i;
+            return (c < n && jx < KB_NB) ? &Z[c + (size_t)jx * n] : nullptr;
+        },
+        (K1p + KB_NB) / KB_TU_KC);
 }
 
 __global__ void __launch_bounds__(256) k_hess_update(const KbItem* __restrict__ items, const int* __restrict__ perm,
@@ -938,6 +928,29 @@ __global__ void __launch_bounds__(512) k_invit_reg(const KbItem* __restrict__ it
     // dynamic LDS (kb_smem): wpb x MAXC x 64 multipliers
     invit_reg<MAXC>(ctx, n, Hw, n, mu_out + it.line_off, hnorm, X, n, (int)blockIdx.y * wpb + ctx.wave(),
                     (int)gridDim.y * wpb, &weak, reinterpret_cast<cd*>(kb_smem) + (size_t)ctx.wave() * MAXC * 64);
+    __syncthreads();
+    if (threadIdx.x == 0 && weak) atomicOr(&status[item], KB_STAT_INVIT_WEAK);
+}
+
+// The same for members of up to MAXC * 64 = 1280 rows (STREAM form: see InvitRegState); no LDS.
+template <int MAXC>
+__global__ void __launch_bounds__(256) k_invit_big(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                    cd* arena, double* varena, const cd* mu_out, int* status) {
+    const int item = perm[blockIdx.x];
+    const KbItem it = items[item];
+    const int n = it.l;
+    if (n > MAXC * 64) return;                       // host picks MAXC from the largest member of the launch
+    const DevCtx ctx = make_ctx(0);
+    const cd* Hw = arena + it.off[KB_BUF_P];
+    cd* X = arena + it.off[KB_BUF_H];
+    const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
+    __shared__ int weak;
+    if (threadIdx.x == 0) weak = 0;
+    __syncthreads();
+    const int wpb = blockDim.x >> 6;
+    // dynamic LDS (kb_smem): wpb x MAXC x 64 multipliers
+    invit_reg<MAXC, true>(ctx, n, Hw, n, mu_out + it.line_off, hnorm, X, n, (int)blockIdx.y * wpb + ctx.wave(),
+                    (int)gridDim.y * wpb, &weak, nullptr);
     __syncthreads();
     if (threadIdx.x == 0 && weak) atomicOr(&status[item], KB_STAT_INVIT_WEAK);
 }
