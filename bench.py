@@ -133,8 +133,10 @@ def _self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    # 50 steps by default: the timed region is synchronised on both sides, so it contains the fill and the drain of the
+    # three-deep pipeline (about 45 ms each); at ~60 ms per step that is 3 % of the region (7 % with 20 steps)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="ensembles (steps) in flight at once (each has its own plan and three streams; every stream "
@@ -354,7 +356,7 @@ def main():
                     pk.upload(sg)
                     pk.execute(sync=True)
                     ns_plans.append(pk)
-                nst = max(nfl, min(args.steps, 2 * nfl))
+                nst = max(nfl, min(args.steps, 8 * nfl))     # (fill and drain of the pipeline are inside this region too)
                 tn = time.perf_counter()
                 for s in range(nst):
                     if s >= nfl:
