@@ -352,7 +352,11 @@ int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream
             const int tiles = (span + 63) / 64;
             hipLaunchKernelGGL(k_wy_gram, dim3((span + KB_NB + 63) / 64, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm,
                                pl->d_arena, pl->d_varena, mode, s);
-            hipLaunchKernelGGL(k_wy_t, dim3(tiles, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s);
+            if (tiles > 8) {      // large members: T once per member and matrix, then the tile products
+                hipLaunchKernelGGL(k_wy_t, dim3(1, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s, 1);
+                hipLaunchKernelGGL(k_wy_t, dim3(tiles, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s, 2);
+            } else
+                hipLaunchKernelGGL(k_wy_t, dim3(tiles, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s, 0);
             hipLaunchKernelGGL(k_wy_update, dim3(tiles, tiles, ch.count * nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena,
                                pl->d_varena, mode, s, nmat);
         }

@@ -391,7 +391,11 @@ __global__ void __launch_bounds__(256) k_wy_gram(const KbItem* __restrict__ item
 }
 
 __global__ void __launch_bounds__(256) k_wy_t(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
-                                               double* varena, int mode, int step) {
+                                               double* varena, int mode, int step, int part) {
+    // part 0: every column tile forms T itself and multiplies (members of a few tiles: cheaper than another launch);
+    // part 1: one workgroup per member and matrix forms T and leaves it in the workspace; part 2: the tiles multiply with
+    // that T (large members: 19 tiles at n = 1200 would each repeat the 32 serial steps of zlarft - 2 of the 10.8 s of a
+    // C4 step before the split).  Same arithmetic either way.
     const KbItem it = items[perm[blockIdx.y]];
     WyGeom g;
     if (!wy_geom(it, arena, varena, mode, blockIdx.z, g)) return;
@@ -403,24 +407,33 @@ __global__ void __launch_bounds__(256) k_wy_t(const KbItem* __restrict__ items, 
     const cd* Zt = g.ws;
     cd* Yc = g.ws + KB_NB * (size_t)g.n;
     const cd* Gt = g.ws + 2 * KB_NB * (size_t)g.n;
+    cd* Tg = g.ws + 2 * KB_NB * (size_t)g.n + KB_NB * KB_NB;
     __shared__ cd T[KB_NB][KB_NB + 1];
     __shared__ cd col[KB_NB];
     const int t = threadIdx.x;
-    for (int e = t; e < KB_NB * (KB_NB + 1); e += blockDim.x) (&T[0][0])[e] = czero();
-    __syncthreads();
-    // zlarft, forward / columnwise: T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i;  G(l, i) = Gt[i + l NB].
-    // (every column tile of the member repeats these 32 short steps: cheaper than another launch)
-    for (int i = 0; i < KB_NB; ++i) {
-        const cd ti = (kb + i < g.nref) ? g.tau[kb + i] : czero();
-        if (t < i) col[t] = -(ti * Gt[i + t * KB_NB]);
+    if (part == 2) {
+        for (int e = t; e < KB_NB * KB_NB; e += blockDim.x) T[e / KB_NB][e % KB_NB] = Tg[e];
         __syncthreads();
-        if (t < i) {
-            cd acc = czero();
-            for (int l = t; l < i; ++l) cfma(acc, T[t][l], col[l]);
-            T[t][i] = acc;
+    } else {
+        for (int e = t; e < KB_NB * (KB_NB + 1); e += blockDim.x) (&T[0][0])[e] = czero();
+        __syncthreads();
+        // zlarft, forward / columnwise: T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i;  G(l, i) = Gt[i + l NB].
+        for (int i = 0; i < KB_NB; ++i) {
+            const cd ti = (kb + i < g.nref) ? g.tau[kb + i] : czero();
+            if (t < i) col[t] = -(ti * Gt[i + t * KB_NB]);
+            __syncthreads();
+            if (t < i) {
+                cd acc = czero();
+                for (int l = t; l < i; ++l) cfma(acc, T[t][l], col[l]);
+                T[t][i] = acc;
+            }
+            if (t == i) T[i][i] = ti;
+            __syncthreads();
         }
-        if (t == i) T[i][i] = ti;
-        __syncthreads();
+        if (part == 1) {
+            for (int e = t; e < KB_NB * KB_NB; e += blockDim.x) Tg[e] = T[e / KB_NB][e % KB_NB];
+            return;
+        }
     }
     // Yc[c, j] = conj( sum_k T[j, k] Z[k, c] ) = sum_k conj(Zt[c, k]) conj(T[j, k]):  one 64 x 32 MFMA tile, k = NB
     mfma_tile_k<true>(
