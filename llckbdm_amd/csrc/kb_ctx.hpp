@@ -38,6 +38,13 @@ struct DevCtx {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+    // Ordering only: the DS instructions of ONE wavefront execute in issue order, so a read issued after a write - from
+    // whatever lanes - returns the written data without waiting for the write's completion (lgkmcnt); what must not
+    // happen is the compiler moving LDS accesses across this point.
+    __device__ __forceinline__ void lds_order() const {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
     __device__ __forceinline__ char* scratch() const { return smem + KB_RED_BYTES; }
     __device__ __forceinline__ int scratch_bytes() const { return smem_bytes - KB_RED_BYTES; }
 
@@ -146,6 +153,7 @@ struct HostCtx {
     void sync() const {}
     void wave_fence() const {}
     void lds_fence() const {}
+    void lds_order() const {}
     char* scratch() const { return smem + KB_RED_BYTES; }
     int scratch_bytes() const { return smem_bytes - KB_RED_BYTES; }
     double wave_sum(double v) const { return v; }
