@@ -373,7 +373,8 @@ __global__ void __launch_bounds__(256) k_wy_gram(const KbItem* __restrict__ item
     if (c0 >= ncols + KB_NB) return;
     cd* Zt = g.ws;
     cd* Gt = g.ws + 2 * KB_NB * (size_t)g.n;
-    mfma_tile_k<true>(
+    // both operands are contiguous along the contraction index (the rows of Out and of V): k-fastest staging
+    mfma_tile_kx<true, true>(
         [&](int i, int kk) -> cd {                 // rows of the product: columns of C, then the NB columns of V itself
             const int c = c0 + i;
             if (kk >= nrows) return czero();
