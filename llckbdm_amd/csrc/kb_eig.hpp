@@ -715,6 +715,13 @@ __device__ __forceinline__ cd csel2(bool c, cd a, cd b) { return mk(c ? a.x : b.
 // registers instead of 4, so that 20 chunks (1280 rows) fit.
 constexpr int KB_INVIT_BIG_MAXC = 20;     // register chunks of the streaming form: members of up to 1280 rows
 
+// value of lane `src` (any lane, 0..63; out-of-range sources are masked by the caller) through the LDS crossbar
+__device__ __forceinline__ cd kb_lane_from(cd v, int src) {
+    const int a = (src & 63) << 2;
+    return mk(__hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v.x)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v.x))),
+              __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v.y)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v.y))));
+}
+
 template <int MAXC, bool STREAM = false>
 struct InvitRegState {
     cd cand[MAXC], bv[MAXC], nxt[STREAM ? 1 : MAXC];
@@ -920,25 +927,40 @@ __device__ void invit_reg(const DevCtx& ctx, int n, const cd* __restrict__ H, in
                 cd p0 = kb_bcast(cand[0], 0);
                 if (is_zero(p0)) p0 = mk(eps3, 0.0);
                 const cd y0 = cdiv(kb_bcast(bv[0], 0), p0);
-                // x = E_{n-2} ... E_0 y : E_j acts on coordinates (j, j+1); one value is carried
+                // x = E_{n-2} ... E_0 y : E_j acts on coordinates (j, j+1); one value is carried:
+                //     sw_j:  x_j = y_{j+1} - f_j c_j,  c_{j+1} = c_j          else:  x_j = c_j,  c_{j+1} = y_{j+1} - f_j c_j
+                // The carry obeys an affine recurrence c_{j+1} = a_j c_j + b_j, (a_j, b_j) = sw_j ? (1, 0) : (-f_j, y_{j+1}):
+                // per chunk of 64 steps the maps are composed by a lane-parallel prefix scan (six rounds through the LDS
+                // crossbar) instead of 64 serial steps of broadcasts - the chain was more than a quarter of a solve.
                 cd carry = y0;
 #pragma unroll
                 for (int cj = 0; cj < MAXC; ++cj) {
                     const int jhi = (n - 2 < 64 * cj + 63) ? n - 2 : 64 * cj + 63;
-                    cd fch = czero();                              // STREAM: this chunk of the multipliers, one coalesced load
-                    if (STREAM && 64 * cj <= jhi) fch = (lane + 64 * cj <= jhi) ? fmL[lane + 64 * cj] : czero();
-                    for (int j = 64 * cj; j <= jhi; ++j) {
-                        const int lj = j - 64 * cj;
-                        const cd f = STREAM ? kb_bcast(fch, lj) : fmL[j];
-                        const bool sw = (__builtin_amdgcn_readlane((int)swp, lj) >> cj) & 1;
-                        cd b;
-                        if (lj < 63) b = kb_bcast(bv[cj], lj + 1);
-                        else b = kb_bcast(bv[(cj + 1 < MAXC) ? cj + 1 : cj], 0);
-                        const cd t = b - f * carry;
-                        const cd xj = sw ? t : carry;
-                        if (!sw) carry = t;
-                        if (lane == lj) bv[cj] = xj;
+                    if (64 * cj > jhi) continue;
+                    const bool valid = lane + 64 * cj <= jhi;
+                    const cd f = valid ? fmL[lane + 64 * cj] : czero();
+                    const bool sw = ((swp >> cj) & 1u) != 0;
+                    // y_{j+1}: the next lane's entry, lane 63 takes lane 0 of the next chunk
+                    const cd up = kb_lane_from(bv[cj], (lane + 1) & 63);
+                    const cd nx = kb_bcast(bv[(cj + 1 < MAXC) ? cj + 1 : cj], 0);
+                    const cd yn = csel2(lane == 63, nx, up);
+                    const bool idm = sw || !valid;                      // identity map (a swap step or beyond the chain)
+                    cd A = idm ? mk(1.0, 0.0) : -f;
+                    cd B = idm ? czero() : yn;
+#pragma unroll
+                    for (int dsh = 1; dsh < 64; dsh <<= 1) {            // inclusive scan: (A, B)_j <- (A, B)_j o (A, B)_{j - dsh}
+                        const cd Ap = kb_lane_from(A, lane - dsh), Bp = kb_lane_from(B, lane - dsh);
+                        const bool on = lane >= dsh;
+                        const cd nB = A * Bp + B, nA = A * Ap;
+                        B = csel2(on, nB, B);
+                        A = csel2(on, nA, A);
                     }
+                    // the carry entering step j: the composed map of the steps before it applied to the chunk's carry
+                    const cd Ae = kb_lane_from(A, lane - 1), Be = kb_lane_from(B, lane - 1);
+                    const cd cin = (lane == 0) ? carry : Ae * carry + Be;
+                    const cd xj = sw ? yn - f * cin : cin;
+                    if (valid) bv[cj] = xj;
+                    carry = kb_bcast(A, 63) * carry + kb_bcast(B, 63);  // lanes beyond the chain hold identity maps
                 }
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c)
