@@ -1104,9 +1104,25 @@ KB_HD void hqr2_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info, in
             }
             kdefl++;
             if (na < KB2_MS_MIN) {
+                // A block of at most 8: all its eigenvalues at once, by one wavefront on a copy in LDS (the small single-shift
+                // iteration that also backs the shift solver), instead of one global-memory sweep + scan per iteration of
+                // this loop (~16 k cycles each, two or three per eigenvalue).  Eigenvalues only: H is not needed any more.
                 const long long c0 = KB_CLOCK();
-                hqr2_single_sweep(ctx, H, ld, l, i, kdefl);
+                for (int idx = tid; idx < na * na; idx += nt) {
+                    const int r = idx % na, c = idx / na;
+                    S[r + c * na] = (r <= c + 1) ? HH(l + r, l + c) : czero();
+                }
+                ctx.sync();
+                if (ctx.wave() == 0) {
+                    WaveCtx<C> wc{ctx, nullptr, 0};
+                    hqr_eigvals(wc, na, S, na, sh, sinfo);
+                }
+                ctx.sync();
+                for (int r = tid; r < na; r += nt) w[l + r] = sh[r];
+                if (*sinfo != 0) fail = 1;
                 if (stats && tid == 0) { stats->single_sweeps++; stats->cyc_single += KB_CLOCK() - c0; }
+                done = 2;
+                break;
             } else {
                 const long long c_sh0 = KB_CLOCK();
                 int nb = na / 6;                              // 2 nb shifts <= na / 3
