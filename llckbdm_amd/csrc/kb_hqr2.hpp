@@ -701,9 +701,15 @@ KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, con
         // ---- (a) load the diagonal window
         const long long c_a = KB_CLOCK();
         const int wlen = we - ws;
-        for (int idx = tid; idx < wlen * wlen; idx += nt) {
-            const int r = idx % wlen, c = idx / wlen;
-            Hw[r + c * WP] = A.get(ws + r, ws + c);
+        if (C::WS >= 64) {                                  // lane = row, wavefronts stride the columns: no div / mod per element
+            const int r = tid & 63;
+            if (r < wlen)
+                for (int c = tid >> 6; c < wlen; c += nt >> 6) Hw[r + c * WP] = A.get(ws + r, ws + c);
+        } else {
+            for (int idx = tid; idx < wlen * wlen; idx += nt) {
+                const int r = idx % wlen, c = idx / wlen;
+                Hw[r + c * WP] = A.get(ws + r, ws + c);
+            }
         }
         ctx.sync();
         const long long c_b = KB_CLOCK();
@@ -837,9 +843,15 @@ KB_HD void chase2_windowed(const C& ctx, const ACC& A, int l, int i, int nb, con
             tm.ws_last[1] = ws;
         }
         // ---- (c) store the window back
-        for (int idx = tid; idx < wlen * wlen; idx += nt) {
-            const int r = idx % wlen, c = idx / wlen;
-            A.put(ws + r, ws + c, Hw[r + c * WP]);
+        if (C::WS >= 64) {
+            const int r = tid & 63;
+            if (r < wlen)
+                for (int c = tid >> 6; c < wlen; c += nt >> 6) A.put(ws + r, ws + c, Hw[r + c * WP]);
+        } else {
+            for (int idx = tid; idx < wlen * wlen; idx += nt) {
+                const int r = idx % wlen, c = idx / wlen;
+                A.put(ws + r, ws + c, Hw[r + c * WP]);
+            }
         }
         ctx.sync();
         const long long c_d = KB_CLOCK();
