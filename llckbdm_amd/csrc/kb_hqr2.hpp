@@ -235,11 +235,12 @@ __device__ __forceinline__ void strip_unit_dev(const HBuf<AUX>& A, const Win2Geo
         int ta[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int idx = lane + 64 * k;
+            // (line, position) of this lane's k-th element without div / mod: right strip - lanes along the positions
+            // (contiguous rows of a column), k = line; top strip - 8 lanes along the lines (contiguous rows), 8 positions per k
             int ln, sp;
-            if (SIDE == 0) { ln = idx / wlen; sp = idx - ln * wlen; }
-            else { sp = idx / nl; ln = idx - sp * nl; }
-            const bool ok = idx < nl * wlen;
+            if (SIDE == 0) { ln = k; sp = lane; }
+            else { ln = lane & 7; sp = (lane >> 3) + 8 * k; }
+            const bool ok = ln < nl && sp < wlen;
             const int e = SIDE == 0 ? (q0 + ln) * A.ld + ws + sp : (q0 + ln) + (ws + sp) * A.ld;
             ta[k] = ok ? ln * TP + sp : -1;
             v[k] = A.get(ok ? e * 16 : OOB);
@@ -338,11 +339,10 @@ __device__ __forceinline__ void strip_unit_dev(const HBuf<AUX>& A, const Win2Geo
         int go[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int idx = lane + 64 * k;
             int ln, sp;
-            if (SIDE == 0) { ln = idx / wlen; sp = idx - ln * wlen; }
-            else { sp = idx / nl; ln = idx - sp * nl; }
-            const bool ok = idx < nl * wlen;
+            if (SIDE == 0) { ln = k; sp = lane; }
+            else { ln = lane & 7; sp = (lane >> 3) + 8 * k; }
+            const bool ok = ln < nl && sp < wlen;
             const int e = SIDE == 0 ? (q0 + ln) * A.ld + ws + sp : (q0 + ln) + (ws + sp) * A.ld;
             go[k] = ok ? e * 16 : OOB;
             v[k] = T4[ok ? ln * TP + sp : 0];
