@@ -207,3 +207,21 @@ def test_one_pass_bidiagonalisation_panel_matches_two_pass(hs):
         B = np.diag(d1) + np.diag(e1[:m - 1], 1)
         assert np.abs(Q1 @ B @ P1.conj().T - A).max() < 1e-13 * nrm
         assert np.abs(Q1.conj().T @ Q1 - np.eye(m)).max() < 1e-13 and np.abs(P1.conj().T @ P1 - np.eye(m)).max() < 1e-13
+
+
+def test_streaming_replay_matches_reference_replay(hs):
+    """bdsqr_stream_lane (the device replay's per-lane routine: register window, the sweeps of a set as a wavefront) against
+    the reference replay (sweep by sweep from the definition): same factors to rounding; also when the replay resumes at set
+    boundaries (`split`: what the device does while the generator is still running)."""
+    rng = np.random.default_rng(33)
+    hs.hs_svd_stream.argtypes = [P, ctypes.c_int, P, P, P, ctypes.c_int]
+    for m in (40, 97, 150):
+        A = np.asfortranarray(rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
+        L0, R0, s0 = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F"), np.zeros(m)
+        assert hs.hs_svd(A.ctypes.data_as(P), m, L0.ctypes.data_as(P), s0.ctypes.data_as(P), R0.ctypes.data_as(P)) == 0
+        for split in (1, 3, 7):
+            L, R, s = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F"), np.zeros(m)
+            assert hs.hs_svd_stream(A.ctypes.data_as(P), m, L.ctypes.data_as(P), s.ctypes.data_as(P), R.ctypes.data_as(P), split) == 0
+            assert np.array_equal(s, s0)
+            assert np.abs(L - L0).max() < 1e-13 and np.abs(R - R0).max() < 1e-13
+            assert np.abs(L @ np.diag(s) @ R.conj().T - A).max() < 1e-12 * m
