@@ -212,6 +212,13 @@ def main():
             return datasets.config4() + ("C4: N=4096, 32 peaks + sigma=1e-3 noise, m=200..1200 (1001 members), l=m, p=1, q=0",)
         return datasets.config3(count=64, m=512, seed0=seed) + ("C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512",)
 
+    # memory of one plan of this rank's share (five m x m work buffers + the rotation log, ~176 m^2 bytes per member): cap the
+    # ensembles in flight so that all plans fit the GPU (the full C4 on one or two ranks: one in flight)
+    if args.sharded:
+        _, _, ms_probe, _ = workload(0)
+        share = ms_probe[shard_items(ms_probe.astype(np.float64) ** 3, world)[rank]].astype(np.float64)
+        est = float(np.sum(176.0 * share ** 2)) + 2e9
+        nfl = max(1, min(nfl, int(200e9 // est)))
     engines, plans, gather_sizes = [], [], []
     for k in range(nfl):
         if args.sharded:
