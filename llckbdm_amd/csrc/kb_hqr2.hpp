@@ -1126,9 +1126,9 @@ KB_HD void hqr2_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info, in
                 }
                 ctx.sync();
                 if (ctx.wave() == 0) {
-                    WaveCtx<C> wc{ctx, nullptr, 0};
-                    hqr_eigvals(wc, na, S, na, sh, sinfo);
-                }
+                    if (tid == 0) *sinfo = 0;
+                    hqr2_shifts(ctx, na, S, sh, aws, sinfo, nullptr);      // Ehrlich-Aberth on Hyman's recurrence (all roots at
+                }                                                          // once, lane-parallel), the small QR iteration behind it
                 ctx.sync();
                 for (int r = tid; r < na; r += nt) w[l + r] = sh[r];
                 if (*sinfo != 0) fail = 1;
