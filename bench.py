@@ -2,38 +2,39 @@
 """KBDM ensemble throughput on MI355X: `python bench.py --gpus N --steps K --warmup W`.
 
 Metric (BASELINE.json): KBDM solves/sec over an m-range ensemble, N=2048 complex signal.
-Workload at every rank = BASELINE.json configs[1] ("C2"): 16-peak brain-sim signal + seeded
+Default workload at every rank = BASELINE.json configs[1] ("C2"): 16-peak brain-sim signal + seeded
 sigma=1e-3 noise, members m = 100..400 step 2 (151 solves), l = m, p = 1, q = 0.
-One "step" = one pass of the whole pipeline (Hankel -> SVD -> reduced eig -> line lists) over
-that batch, signals already resident in HBM, line lists left in HBM.  With N > 1 every rank
-solves its own ensemble (another noise seed: weak scaling, members are independent) and the
-packed results are gathered to every rank with ONE grouped RCCL transfer (kbdm_plan_gather of the
-C ABI: device buffers to device buffers over xGMI) inside the timed region.  `--sharded` instead
-deals ONE ensemble (default C4: 1001 members, N=4096) over the ranks (strong scaling, the
-partition of llckbdm_amd.distributed.shard_items) with the same gather.  torch.distributed is the
-process launcher and the control plane only (gloo: barrier, max over ranks, id hand-off).
-`python bench.py --gpus N` without a launcher starts its own ranks (torch.distributed.run).
+One "step" = one whole ensemble through the pipeline (Hankel -> SVD -> reduced eig -> line lists), submitted
+through the package's public scheduler `Engine.submit` / `Pending.result` (three ensembles in flight on three
+contexts); `value` is measured with the signals already resident in HBM and the results landing in host memory,
+`host_to_host` with the upload inside the loop as well (the unit sampling.py:52-70 defines).
+With N > 1 ranks (one process per GPU; the launcher's RANK / LOCAL_RANK / WORLD_SIZE are read from the environment):
+  default      every rank solves its own ensembles (another noise seed: weak scaling, members are independent) and
+               the packed results are gathered to rank 0 with ONE grouped RCCL transfer per step (kbdm_plan_gather
+               of the C ABI: device buffers to device buffers over xGMI) inside the timed region;
+  --sharded    ONE job dealt over the ranks by LPT on m^3 (llckbdm_amd.distributed.shard_items) with the same gather:
+               --workload C5 (default: 64 voxels x 256 members) or C4 (m = 200..1200, N = 4096) - strong scaling.
+The control plane (rank 0's communicator id, barrier, max over ranks) is llckbdm_amd.launch.Rendezvous: one TCP
+socket per rank, standard library only.  `python bench.py --gpus N` without a launcher starts its own ranks.
 
 The JSON line also carries
-  roofline     : the dominant kernel's algorithmic FP64 flops / its HIP-event duration vs the
-                 FP64 matrix peak (flop model: SURVEY.md 8d, stated in DESIGN.md)
-  cpu_baseline : the numpy/scipy oracle (the reference's own LAPACK calls) timed on the host
-                 cores of this box on a bounded sample of the same workload (rank 0, N=1 only):
-                 one process per core (best effort) and, as `serial`, the shape the reference ships
-                 (sampling.py:52-62: one loop, default BLAS threads).
-  host_inclusive : the same ensemble from host signals to host line lists (plan reused: H2D +
-                 execute + D2H), SURVEY.md 8d's wording of the metric.
-  north_star_workload : the m = 100..500 ensemble BASELINE.json's target is quoted on.
+  roofline     : the dominant kernel's algorithmic FP64 flops / its HIP-event duration (events recorded by the library
+                 on the stream the kernel runs on) vs the FP64 peak (flop model: SURVEY.md 8d, stated in DESIGN.md)
+  cpu_baseline : the numpy/scipy oracle (the reference's own LAPACK calls) timed on the host cores of this box on a
+                 bounded sample of the same workload (rank 0, N=1 only): one process per core (best effort) and, as
+                 `serial`, the shape the reference ships (sampling.py:52-62: one loop, default BLAS threads).
+  other_configs: short runs of the other BASELINE.json configurations (C3, C4, C5) and of the north-star ensemble
+                 m = 100..500 through the same public API (N=1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-# The pipeline runs on three HIP streams; torch and RCCL add their own.  With the runtime's default of four
-# hardware queues those streams would share queues (measured: 194 instead of 175 ms per step in the
-# multi-process path), so ask for eight before anything initialises HIP.
+# Three contexts x three HIP streams; RCCL adds its own.  With the runtime's default of four hardware queues those
+# streams would share queues, so ask for sixteen before anything initialises HIP.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
@@ -116,18 +117,77 @@ def cpu_baseline_serial(sig, ms, dwell, stride=5):
                       f"BLAS threads, as sampling.py:52-62 ships it, {dt:.1f} s wall"}
 
 
-def _self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start N ranks as child processes (never re-exec this one:
-    nothing here has touched the GPU yet, but a child keeps the contract simple) and forward rank 0's line."""
-    import socket
-    import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd).returncode
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def file_sha(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+WORKLOADS = {
+    "C2": "C2: N=2048, 16 peaks + sigma=1e-3 noise, m=100..400:2 (151 members), l=m, p=1, q=0",
+    "NS": "NS: N=2048, 16 peaks + sigma=1e-3 noise, m=100..500:2 (201 members), l=m, p=1, q=0",
+    "C3": "C3: N=2048, 1024 pseudo-noise draws (sigma=1e-6), m=512, l=m, p=1, q=0",
+    "C3small": "C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512",
+    "C4": "C4: N=4096, 32 peaks + sigma=1e-3 noise, m=200..1200 (1001 members), l=m, p=1, q=0",
+    "C5": "C5: 64 voxels (N=2048, 16 peaks with scaled amplitudes + sigma=1e-3 noise) x m=128..383 (16384 members)",
+}
+
+
+def make_workload(name, seed):
+    from llckbdm_amd import datasets
+    if name == "C2":
+        return datasets.config2(seed=seed)
+    if name == "NS":
+        return datasets.north_star(seed=seed)
+    if name == "C3":
+        return datasets.config3(count=1024, m=512, seed0=seed)
+    if name == "C3small":
+        return datasets.config3(count=64, m=512, seed0=seed)
+    if name == "C4":
+        return datasets.config4()
+    if name == "C5":
+        return datasets.config5()
+    raise ValueError(name)
+
+
+def plan_bytes_estimate(ms):
+    # five m x m work buffers + the rotation log, ~176 m^2 bytes per member
+    return float(np.sum(176.0 * np.asarray(ms, dtype=np.float64) ** 2)) + 2e9
+
+
+def run_api_loop(eng, works, steps, nfl, resident, on_done=None):
+    """`steps` ensembles through Engine.submit with `nfl` in flight; returns elapsed seconds.  works[k] = (signals,
+    sig_idx, ms) of the ensemble that step s = k (mod nfl) solves.  on_done(pending) runs when a step is retired."""
+    from collections import deque
+    pend = deque()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        if len(pend) == nfl:
+            h = pend.popleft()
+            if on_done:
+                on_done(h)
+            h.result(check=False)
+        sg, si, mm = works[s % nfl]
+        pend.append(eng.submit(sg, si, mm, mm, p=1, q=0.0, dwell=DWELL, resident=resident))
+    while pend:
+        h = pend.popleft()
+        if on_done:
+            on_done(h)
+        h.result(check=False)
+    return time.perf_counter() - t0
+
+
+DWELL = 5e-4
 
 
 def main():
@@ -139,20 +199,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
-                    help="ensembles (steps) in flight at once (each has its own plan and three streams; every stream "
-                         "needs a hardware queue of its own: GPU_MAX_HW_QUEUES, 16 asked for here)")
-    ap.add_argument("--workload", default=None, choices=["C2", "NS", "C3small", "C4"],
-                    help="C2 (default), NS = north-star ensemble m=100..500, C3small, C4 (default of --sharded)")
+                    help="ensembles (steps) in flight at once (Engine(in_flight=...): one context = three streams each; "
+                         "every stream needs a hardware queue of its own: GPU_MAX_HW_QUEUES, 16 asked for here)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="C2 (default), NS = north-star ensemble m=100..500, C3, C3small, C4, C5 (default of --sharded)")
     ap.add_argument("--sharded", action="store_true",
-                    help="strong scaling: ONE ensemble dealt over the ranks (shard_items) + the RCCL gather per step")
-    ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / north_star_workload")
+                    help="strong scaling: ONE job dealt over the ranks (shard_items) + the RCCL gather per step")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_to_host / other_configs")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
-                    help="submit the second ensemble at once instead of when the first reaches its QR iteration")
+                    help="submit the ensembles of a burst at once instead of a fraction of a cycle apart")
     args = ap.parse_args()
     if args.workload is None:
-        args.workload = "C4" if args.sharded else "C2"
+        args.workload = "C5" if args.sharded else "C2"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(_self_launch(args))
+        from llckbdm_amd.launch import spawn
+        sys.exit(spawn([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     # stdout carries exactly one line (the JSON): anything a library prints there while we run (RCCL's version
     # banner at communicator creation, for one) goes to stderr
@@ -163,229 +224,143 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    torch = None
     # KBDM_BENCH_FORCE_DIST=1: take the multi-process path (RCCL init, device-side gather) even with one rank -
     # a rehearsal of the N > 1 code on a one-GPU box
-    force_dist = os.environ.get("KBDM_BENCH_FORCE_DIST") == "1"
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
+    multi = world > 1 or os.environ.get("KBDM_BENCH_FORCE_DIST") == "1"
 
-    from llckbdm_amd import datasets
+    from llckbdm_amd import _lib
+    from llckbdm_amd.distributed import RcclComm, packed_bytes, shard_items, unpack_block
     from llckbdm_amd.engine import Engine
+    from llckbdm_amd.launch import Rendezvous
 
-    comm_box = [None]
+    rdzv = Rendezvous(rank, world) if multi else None
+    wname = WORKLOADS[args.workload]
+    big = args.workload in ("C3", "C4", "C5")
 
-    def init_dist():
-        # after the solver's streams exist: the runtime hands out hardware queues in order of stream creation,
-        # and the communicator's streams (idle most of the time) should be the ones that share.  torch.distributed
-        # (gloo, CPU) is the control plane; the data path is the library's own RCCL communicator.
-        if dist is None:
-            return
-        if world > 1 or "MASTER_ADDR" in os.environ:
-            dist.init_process_group("gloo")
-        else:                                   # one-rank rehearsal without a launcher
-            dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
-        from llckbdm_amd.distributed import RcclComm
-
-        def exchange(uid):
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        comm_box[0] = RcclComm(engines[0], world, rank, exchange, force=True)
-
-    # Ensembles in flight: every step solves one whole ensemble (its own plan, workspace and streams); a step
-    # is submitted without waiting for the previous one, and a plan is waited for only when its workspace is
-    # needed again.  One ensemble alone is latency bound (a chain of one-CU-per-member kernels, most of the
-    # 256 CUs idle); two or three in flight overlap those chains.  `step_latency_ms` is the single-ensemble latency.
+    # ---- this rank's work: works[k] = the ensemble a step with k = s mod nfl solves
     nfl = max(1, args.in_flight)
-    dwell = datasets.DWELL
-    from llckbdm_amd.distributed import packed_bytes, shard_items
-
-    def workload(seed):
-        if args.workload == "C2":
-            return datasets.config2(seed=seed) + ("C2: N=2048, 16 peaks + sigma=1e-3 noise, m=100..400:2 (151 members), l=m, p=1, q=0",)
-        if args.workload == "NS":
-            return datasets.north_star(seed=seed) + ("NS: N=2048, 16 peaks + sigma=1e-3 noise, m=100..500:2 (201 members), l=m, p=1, q=0",)
-        if args.workload == "C4":
-            return datasets.config4() + ("C4: N=4096, 32 peaks + sigma=1e-3 noise, m=200..1200 (1001 members), l=m, p=1, q=0",)
-        return datasets.config3(count=64, m=512, seed0=seed) + ("C3small: N=2048, 64 pseudo-noise draws (sigma=1e-6), m=512",)
-
-    # memory of one plan of this rank's share (five m x m work buffers + the rotation log, ~176 m^2 bytes per member): cap the
-    # ensembles in flight so that all plans fit the GPU (the full C4 on one or two ranks: one in flight)
+    parts = None
     if args.sharded:
-        _, _, ms_probe, _ = workload(0)
-        share = ms_probe[shard_items(ms_probe.astype(np.float64) ** 3, world)[rank]].astype(np.float64)
-        est = float(np.sum(176.0 * share ** 2)) + 2e9
-        nfl = max(1, min(nfl, int(200e9 // est)))
-    engines, plans, gather_sizes = [], [], []
-    for k in range(nfl):
-        if args.sharded:
-            # ONE ensemble per step, its members dealt over the ranks (every rank derives the same table)
-            sigs, sig_idx, ms_all, wname = workload(1000 * k)
-            parts = shard_items(ms_all.astype(np.float64) ** 3, world)
-            mine = parts[rank]
-            ms, sidx = ms_all[mine], sig_idx[mine]
-            gather_sizes.append(np.array([packed_bytes(ms_all[ix].sum(), ms_all[ix].sum(), len(ix)) for ix in parts],
-                                         dtype=np.int64))
-            units = len(ms_all)
-        else:
-            sigs, sidx, ms, wname = workload(rank + 1000 * k)
-            gather_sizes.append(np.array([packed_bytes(ms.sum(), ms.sum(), len(ms))] * world, dtype=np.int64))
-            units = len(ms)
-        e = Engine(local_rank)
-        pk = e.plan(sigs.shape[0], sigs.shape[1], sidx, ms, ms, p=1, q=0.0, dwell=dwell)
-        pk.upload(sigs)
-        engines.append(e)
-        plans.append(pk)
-    plan = plans[0]
-    init_dist()
-    comms = []
-    if dist is not None:
-        from llckbdm_amd.distributed import RcclComm
+        sigs_all, sidx_all, ms_all = make_workload(args.workload, 0)
+        parts = shard_items(ms_all.astype(np.float64) ** 3, world)
+        mine = parts[rank]
+        used = np.unique(sidx_all[mine])
+        remap = np.zeros(sigs_all.shape[0], dtype=np.int32)
+        remap[used] = np.arange(len(used), dtype=np.int32)
+        my = (np.ascontiguousarray(sigs_all[used]), remap[sidx_all[mine]], ms_all[mine])
+        nfl = max(1, min(nfl, int(200e9 // plan_bytes_estimate(my[2])))) if not big else 1
+        works = [my] * nfl
+        units = len(ms_all)
+        sizes = np.array([packed_bytes(ms_all[ix].sum(), ms_all[ix].sum(), len(ix)) for ix in parts], dtype=np.int64)
+    else:
+        if big:
+            nfl = 1
+        works = [make_workload(args.workload, rank + 1000 * k) for k in range(nfl)]
+        units = len(works[0][2])
+        sizes = np.array([packed_bytes(works[0][2].sum(), works[0][2].sum(), units)] * world, dtype=np.int64)
+    ms = works[0][2]
 
-        def exchange(uid):
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        comms = [comm_box[0]] + [RcclComm(engines[k], world, rank, exchange, force=True) for k in range(1, nfl)]
-    sigs0 = workload(rank)[0] if args.workload in ("C2", "NS") else None
+    eng = Engine(local_rank, in_flight=nfl)
+    eng.stagger = args.stagger
+    ctxs = eng.ensure_contexts()
+    # the communicators come AFTER the solver's streams: the runtime hands out hardware queues in order of stream
+    # creation, and the communicator's streams (idle most of the time) should be the ones that share
+    comms = {}
+    if multi:
+        for c in ctxs:
+            comms[c.value] = RcclComm(eng, world, rank, rdzv.exchange_id, force=True, ctx=c)
 
-    def sync_all():
-        for pk in plans:
-            pk.sync()
-
-    stage_acc = {}
-    busy = [False] * nfl
+    stage_acc, nstage = {}, [0]
     timed = [False]
+    gathered_ok = [True]
 
-    def finish(k):
-        """Complete the step that plan k is running: wait, (multi-process) gather its line lists, stage timers."""
-        if not busy[k]:
-            return
-        pk = plans[k]
-        if dist is not None:
-            # the one collective of the path: every rank's packed block, device to device (waits for the plan)
-            comms[k].engine.lib.kbdm_plan_gather(pk.handle, world, rank, gather_sizes[k].ctypes.data, -1, None)
+    def on_done(h):
+        """Retire a step: (multi-process) the one collective of the path, then the stage timers of its run."""
+        if multi:
+            comm = comms[h._slot.ctx.value]
+            comm.gather_plan(h.plan, sizes, root=0 if not args.sharded else 0)        # checked return code; waits
         if timed[0]:
-            for name, v in pk.stage_ms().items():      # HIP events of the critical lane (waits for the plan)
+            for name, v in h.plan.stage_ms().items():      # HIP events of the critical lane (waits for the plan)
                 stage_acc[name] = stage_acc.get(name, 0.0) + v
-        else:
-            pk.sync()
-        busy[k] = False
+            nstage[0] += 1
 
-    def step(s):
-        k = s % nfl
-        finish(k)
-        if timed[0] and 1 <= s < nfl and args.stagger:
-            # the pipelines have the same cycle: started together they stay in phase (panels against panels,
-            # QR iteration against QR iteration); start each one a fraction of the cycle after the one before it
-            # (two in flight: when the first reaches its QR iteration)
-            plans[s - 1].wait_stage({2: "k_hess", 3: "k_bdsqr_sort"}.get(nfl, "k_svd_fac"))
-        plans[k].execute(sync=False)
-        busy[k] = True
+    def sync_ranks():
+        eng.drain()
+        if rdzv is not None:
+            rdzv.barrier()
 
-    # warm-up: one ensemble at a time, which also gives the single-ensemble latency
+    # warm-up: one ensemble at a time, which also gives the single-ensemble latency; every context runs once
     latency = None
-    for s in range(args.warmup):
-        sync_all()
-        tw = time.perf_counter()
-        step(s)
-        finish(s % nfl)
-        sync_all()
-        tw = time.perf_counter() - tw
+    for s in range(max(args.warmup, nfl)):
+        tw = run_api_loop(eng, [works[s % nfl]], 1, 1, resident=True, on_done=on_done)
         latency = tw if latency is None else min(latency, tw)
-    for k in range(nfl):               # every plan has run once before the timed region
-        if args.warmup <= k:
-            step(k)
-            finish(k)
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    sync_all()
+    run_api_loop(eng, works, nfl, nfl, resident=True, on_done=on_done)      # every context holds its plan + signals
+    sync_ranks()
     timed[0] = True
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s)
-    for s in range(args.steps, args.steps + nfl):     # drain in submission order
-        finish(s % nfl)
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    sync_all()
+    run_api_loop(eng, works, args.steps, nfl, resident=True, on_done=on_done)
+    sync_ranks()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if rdzv is not None:
+        elapsed = rdzv.max(elapsed)
+    timed[0] = False
 
-    ok = min(int((pk.download().status == 0).sum()) for pk in plans)
-    if dist is not None and world == 1:
-        # one-rank rehearsal: the gathered block must be exactly the plan's results
-        from llckbdm_amd.distributed import unpack_block
-        buf = comms[0].gather_plan(plans[0], gather_sizes[0])
-        ref = plans[0].download()
-        ll, sv, st, kp = unpack_block(buf, plans[0].total_lines, plans[0].total_sv, plans[0].B)
-        assert np.array_equal(ll, ref.lines) and np.array_equal(sv, ref.sv) and np.array_equal(kp, ref.keep.astype(bool))
+    # ---- verification outside the timed region: every member converged; (multi) the gathered blocks are the results
+    last = eng.submit(*works[0][:3], works[0][2], p=1, q=0.0, dwell=DWELL, resident=True)
+    ref = last.result(check=False)
+    ok = int((ref.status == 0).sum())
+    if multi:
+        buf = comms[last._slot.ctx.value].gather_plan(last.plan, sizes, root=-1)       # to every rank, for the check
+        off = int(sizes[:rank].sum())
+        ll, sv, st, kp = unpack_block(buf[off:off + int(sizes[rank])], int(ms.sum()), int(ms.sum()), len(ms))
+        gathered_ok[0] = bool(np.array_equal(ll, ref.lines) and np.array_equal(sv, ref.sv) and
+                              np.array_equal(st, ref.status) and np.array_equal(kp, ref.keep.astype(bool)))
+        flags = rdzv.allgather(bytes([1 if gathered_ok[0] else 0]) + int(ok).to_bytes(4, "little"))
+        gathered_ok[0] = all(f[0] == 1 for f in flags)
+        ok_all = [int.from_bytes(f[1:5], "little") for f in flags]
+    else:
+        ok_all = [ok]
 
-    # the same steps one at a time (outside the timed region; reported next to the headline for comparison)
-    serial = host_incl = ns_line = None
-    if dist is None:
-        timed[0] = False
+    # ---- the same steps one at a time, host -> host, and the other configurations (N = 1 only)
+    serial = host_incl = None
+    others = {}
+    if not multi:
         ns_ser = min(args.steps, 5)
         if nfl > 1:
-            ts = time.perf_counter()
-            for s in range(ns_ser):
-                plans[0].execute(sync=True)
-            ts = time.perf_counter() - ts
+            ts = run_api_loop(eng, [works[0]], ns_ser, 1, resident=True)
             serial = {"value": units * ns_ser / ts, "ms_per_step": 1e3 * ts / ns_ser, "steps": ns_ser, "ensembles_in_flight": 1}
         if not args.no_extras:
-            # SURVEY.md 8d's wording of the metric: host signals resident -> host line lists resident, with the plan
-            # (device workspace) reused as Engine.solve does for a repeated geometry
-            sig_host = np.ascontiguousarray(workload(rank)[0])
-            th = time.perf_counter()
-            for s in range(ns_ser):
-                plans[0].upload(sig_host)
-                plans[0].execute(sync=False)
-                plans[0].download()
-            th = time.perf_counter() - th
-            host_incl = {"value": units * ns_ser / th, "unit": "solves/s", "ms_per_step": 1e3 * th / ns_ser, "steps": ns_ser,
-                         "ensembles_in_flight": 1, "includes": "H2D of the signal + execute + D2H of lines, sv, mu, keep, status"}
-            if args.workload == "C2" and not args.sharded:
-                # the ensemble the north-star target is quoted on (m = 100..500), same number of ensembles in flight
-                for pk in plans[1:]:
-                    pk.close()
-                ns_plans = []
-                for k in range(nfl):
-                    sg, si, mm = datasets.north_star(seed=rank + 1000 * k)
-                    pk = engines[k].plan(1, sg.shape[1], si, mm, mm, p=1, q=0.0, dwell=dwell)
-                    pk.upload(sg)
-                    pk.execute(sync=True)
-                    ns_plans.append(pk)
-                nst = max(nfl, min(args.steps, 8 * nfl))     # (fill and drain of the pipeline are inside this region too)
-                tn = time.perf_counter()
-                for s in range(nst):
-                    if s >= nfl:
-                        ns_plans[s % nfl].sync()
-                    ns_plans[s % nfl].execute(sync=False)
-                for pk in ns_plans:
-                    pk.sync()
-                tn = time.perf_counter() - tn
-                t1 = time.perf_counter()
-                ns_plans[0].execute(sync=True)
-                t1 = time.perf_counter() - t1
-                ns_ok = int((ns_plans[0].download().status == 0).sum())
-                ns_line = {"workload": "N=2048, 16 peaks + sigma=1e-3 noise, m=100..500:2 (201 members)",
-                           "value": len(mm) * nst / tn, "unit": "solves/s", "ms_per_step": 1e3 * tn / nst, "steps": nst,
-                           "ensembles_in_flight": nfl, "one_ensemble_at_a_time": len(mm) / t1, "members_ok": ns_ok}
+            # SURVEY.md 8d's wording of the metric: host signals resident -> host line lists resident, through the same
+            # public API, the same number of ensembles in flight
+            nh = args.steps
+            th = run_api_loop(eng, works, nh, nfl, resident=False)
+            th1 = run_api_loop(eng, [works[0]], ns_ser, 1, resident=False)
+            host_incl = {"value": units * nh / th, "unit": "solves/s", "ms_per_step": 1e3 * th / nh, "steps": nh,
+                         "ensembles_in_flight": nfl, "one_ensemble_at_a_time": units * ns_ser / th1,
+                         "includes": "Engine.submit -> Pending.result: staging + H2D of the signal, every kernel, D2H of "
+                                     "lines, sv, mu, keep, status"}
+            if args.workload == "C2":
+                eng.clear_plan_cache()
+                for name, steps_o, fl_o in (("NS", 8 * nfl, nfl), ("C3", 2, 1), ("C5", 1, 1), ("C4", 1, 1)):
+                    try:
+                        w = [make_workload(name, 1000 * k) for k in range(fl_o)]
+                        run_api_loop(eng, w, fl_o, fl_o, resident=False)                     # plans + warm-up
+                        to = run_api_loop(eng, w, steps_o, fl_o, resident=False)
+                        chk = eng.submit(*w[0][:3], w[0][2], p=1, q=0.0, dwell=DWELL).result(check=False)
+                        others[name] = {"workload": WORKLOADS[name], "value": len(w[0][2]) * steps_o / to, "unit": "solves/s",
+                                        "ms_per_step": 1e3 * to / steps_o, "steps": steps_o, "ensembles_in_flight": fl_o,
+                                        "members": int(len(w[0][2])), "members_ok": int((chk.status == 0).sum()),
+                                        "timed": "host -> host through Engine.submit"}
+                    except Exception as e:       # informational lines: never lose the headline over them
+                        others[name] = {"error": repr(e)}
+                    eng.clear_plan_cache()
 
     if rank == 0:
         value = (1 if args.sharded else world) * units * args.steps / elapsed
-        stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+        stage_ms = {k: v / max(1, nstage[0]) for k, v in stage_acc.items()}
         # stage timers are those of lane 0 (the largest members, the critical path): price its launches
         # with the flops of exactly those members; `pipeline_tflops` below uses all members
-        n0 = plan.lane0_members()
+        n0 = last.plan.lane0_members()
         lane0 = sorted((int(m) for m in ms), reverse=True)[:n0]
         fl, fl_all = {}, {}
         for m in lane0:
@@ -397,8 +372,7 @@ def main():
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
         # the kernel behind the dominant stage timer (lane 0 runs the QR iteration as the team kernel)
-        hqr_v2 = os.environ.get("KBDM_HQR_V", "2") != "1"
-        kname = {"k_hqr": "k_hqr2_team" if hqr_v2 else "k_hqr_team", "k_svd_fac": "k_bidiag_panel<0>", "k_hess": "k_hess_panel",
+        kname = {"k_hqr": "k_hqr2_team", "k_svd_fac": "k_bidiag_panel<0>", "k_hess": "k_hess_panel",
                  "k_gen(Q,P)": "k_gen<8>", "k_bdsqr_apply": "k_bdsqr_stream", "k_invit": "k_invit_reg<8>"}.get(dom, dom)
         # HBM bytes per launch of that kernel: NOT measured by this run - taken from the newest committed PMC passes
         # (profiles/*_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command), if any
@@ -429,35 +403,43 @@ def main():
             "scaling": "strong" if args.sharded else "weak",
             "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
             "config": {"workload": wname, "members_per_gpu": len(ms), "members_per_step": units * (1 if args.sharded else world),
-                       "parallelism": (f"one ensemble sharded over {world} rank(s) by LPT on m^3" if args.sharded
+                       "parallelism": (f"one job sharded over {world} rank(s) by LPT on m^3" if args.sharded
                                        else f"one ensemble per rank x{world}"),
                        "ensembles_in_flight": nfl,
-                       "collective": ("one grouped RCCL send/recv of the packed results per step (kbdm_plan_gather)"
-                                      if dist is not None else "none")},
+                       "api": "llckbdm_amd.engine.Engine.submit / Pending.result (the product's scheduler)",
+                       "timed_region": "signals resident in HBM -> results in host memory (host -> host: `host_to_host`)",
+                       "collective": ("one grouped RCCL send/recv of the packed results to rank 0 per step (kbdm_plan_gather)"
+                                      if multi else "none")},
             "roofline": roofline,
-            "pipeline_tflops": total_fl * args.steps * world / elapsed / 1e12,
+            "pipeline_tflops": total_fl * args.steps * (1 if args.sharded else world) / elapsed / 1e12,
             "stage_ms": stage_ms,
             "step_latency_ms": None if latency is None else 1e3 * latency,
             "one_ensemble_at_a_time": serial,
-            "host_inclusive": host_incl,
-            "north_star_workload": ns_line,
-            "members_ok": ok,
+            "host_to_host": host_incl,
+            "other_configs": others or None,
+            "members_ok": min(ok_all), "members_ok_per_rank": ok_all,
+            "gathered_blocks_verified": gathered_ok[0] if multi else None,
+            "git_head": git_head(), "bench_sha256_16": file_sha(os.path.abspath(__file__)),
+            "lib_sha256_16": file_sha(_lib.LIB_PATH),
         }
-        if world == 1 and dist is None and not args.no_cpu_baseline:
+        if world == 1 and not multi and not args.no_cpu_baseline:
             try:
                 if args.workload in ("C2", "NS"):
-                    out["cpu_baseline"] = cpu_baseline(sigs0[0], ms, dwell)
-                    out["cpu_baseline"]["serial"] = cpu_baseline_serial(sigs0[0], ms, dwell)
+                    sig0 = make_workload(args.workload, rank)[0][0]
+                    out["cpu_baseline"] = cpu_baseline(sig0, ms, DWELL)
+                    out["cpu_baseline"]["serial"] = cpu_baseline_serial(sig0, ms, DWELL)
                 else:
                     out["cpu_baseline"] = None
             except Exception as e:   # the baseline is informational; never lose the GPU number over it
                 out["cpu_baseline"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        for c in comms:
-            c.close()
-        dist.destroy_process_group()
+    for c in comms.values():
+        c.close()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
+    eng.close()
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KBDM_ABI_VERSION 1
+#define KBDM_ABI_VERSION 2
 
 #define KBDM_OK 0
 #define KBDM_E_INVALID (-1)   /* bad argument (sizes, null pointers, m/l/p constraint) */
@@ -76,6 +76,29 @@ int kbdm_plan_execute(kbdm_plan* plan);                            /* enqueue ev
 int kbdm_plan_sync(kbdm_plan* plan);                               /* wait for the stream   */
 int kbdm_plan_download(kbdm_plan* plan, double* lines, double* sv, double* mu, uint8_t* keep,
                        int32_t* status);                           /* D2H (null = skip)     */
+/* Host -> host without a blocking copy (the unit the metric counts: llckbdm/sampling.py:52-70 takes host data and
+ * returns host line lists): kbdm_plan_submit copies the signals (S*N complex128; null = keep the uploaded ones) into
+ * the plan's pinned staging buffer and enqueues H2D, every kernel and the D2H of all outputs; it returns at once, so
+ * that several plans (on different contexts) can be in flight.  kbdm_plan_collect waits for the plan and copies the
+ * results out (null = skip).  One submit per collect. */
+int kbdm_plan_submit(kbdm_plan* plan, const double* signals_host);
+int kbdm_plan_collect(kbdm_plan* plan, double* lines, double* sv, double* mu, uint8_t* keep, int32_t* status);
+
+/* Conservative execution modes of a plan, used by the host for the ONE retry of members whose status word reports
+ * non-convergence before it raises (scipy.linalg.svd / eig raise LinAlgError there: llckbdm/kbdm.py:166,192):
+ *   KBDM_MODE_SAFE_REPLAY  the rotation replay of the bidiagonal SVD waits for its generator through a stream
+ *                          dependency instead of following it through in-kernel flags
+ *   KBDM_MODE_SOLO_QR      every member's QR iteration runs in one workgroup (no chase + helper teams) */
+#define KBDM_MODE_SAFE_REPLAY 1
+#define KBDM_MODE_SOLO_QR 2
+int kbdm_plan_set_mode(kbdm_plan* plan, int mode);
+/* 1 if this context defaults to KBDM_MODE_SAFE_REPLAY because the streams of this process outnumber the hardware
+ * queues the runtime was initialised with (GPU_MAX_HW_QUEUES) */
+int kbdm_ctx_safe_replay(const kbdm_ctx* ctx);
+/* device bytes a plan of this geometry will allocate (before chunking) / a plan holds */
+int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l);
+int64_t kbdm_plan_workspace_bytes(const kbdm_plan* plan);
+
 /* device-resident outputs (for a collective over xGMI without a host bounce) */
 void* kbdm_plan_lines_device(kbdm_plan* plan);
 void* kbdm_plan_sv_device(kbdm_plan* plan);

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,7 @@ using namespace kb;
 namespace {
 
 thread_local std::string g_err;
+std::atomic<int> g_streams{0};      // HIP streams created by this library in this process (all contexts)
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -116,6 +118,9 @@ struct kbdm_ctx {
     int win_hqr2 = KB2_WIN_DEV;   // its LDS window (fixed: the device chase is compiled for it)
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
+    int nstreams = 0;     // HIP streams this context created
+    int safe_replay = 0;  // 1: the rotation replay waits for the generators through a stream dependency (no in-kernel
+                          // hand-off): the default when the process cannot give every stream a hardware queue of its own
     // multi-GPU: RCCL communicator (one per context) and the device buffers of the packed gather
     void* comm = nullptr;
     int comm_world = 0, comm_rank = 0;
@@ -159,6 +164,12 @@ struct kbdm_plan {
     char* d_rings = nullptr;       // KB_TEAM_SLOTS records per member
     float stage_ms[KBDM_NSTAGES] = {0};
     bool timed = false;
+    int mode = 0;                  // KBDM_MODE_* bits (kbdm_plan_set_mode)
+    // pinned host staging of kbdm_plan_submit / kbdm_plan_collect (host -> host without a blocking copy)
+    cd* h_signals = nullptr;
+    char* h_out = nullptr;
+    size_t h_out_bytes = 0;
+    bool submitted = false;
 };
 
 namespace {
@@ -428,7 +439,8 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     // generators of large members are still running.  Only when every generator wavefront is
     // certainly resident before the replay starts (they were launched a whole kernel earlier and
     // need one wavefront each); otherwise a stream dependency.
-    const bool flag_mode = ch.count <= 2048 && env_int("KBDM_BDSQR_FLAG", 1) != 0;
+    const bool flag_mode = ch.count <= 2048 && !(pl->mode & KBDM_MODE_SAFE_REPLAY) &&
+                           env_int("KBDM_BDSQR_FLAG", ctx->safe_replay ? 0 : 1) != 0;
     {
         int r = launch_gen(pl, ch, ch.mmax, 0, 2, st);
         if (r) return r;
@@ -511,7 +523,8 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         // Large members of the critical lane run as two-workgroup teams (k_hqr_team); the remaining
         // members of the chunk run solo on the side stream (after k_gen(Qh)), concurrently.
         int nteam = 0;
-        if (ctx->team_hqr && win > 0 && ln.stream2 != ln.stream && (ch.lane == 0 || ctx->team_hqr > 1)) {
+        if (ctx->team_hqr && !(pl->mode & KBDM_MODE_SOLO_QR) && win > 0 && ln.stream2 != ln.stream &&
+            (ch.lane == 0 || ctx->team_hqr > 1)) {
             int nside = 0;                                   // lanes that may run teams share the budget of resident teams
             for (int i = 0; i < ctx->nlanes; ++i) nside += (ctx->lanes[i].stream2 != ctx->lanes[i].stream) ? 1 : 0;
             const int cap = std::max(1, ctx->team_max / std::max(1, nside));
@@ -675,25 +688,37 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     kbdm_ctx* c = new kbdm_ctx();
     c->device = device;
     c->nlanes = std::min(KB_MAX_LANES, std::max(1, env_int("KBDM_LANES", c->nlanes)));
-    const int hwq = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
+    // hardware queues the runtime was initialised with: the host may know better than the environment (KBDM_HW_QUEUES:
+    // HIP was initialised before GPU_MAX_HW_QUEUES was set)
+    const int hwq = std::max(1, env_int("KBDM_HW_QUEUES", env_int("GPU_MAX_HW_QUEUES", 4)));
     const bool side_all = env_int("KBDM_SIDE_ALL", 0) != 0;
     if (const char* v = getenv("KBDM_LANE0_FRAC")) c->lane0_frac = std::min(0.95, std::max(0.05, atof(v)));
     for (int i = 0; i < c->nlanes; ++i) {
         Lane& ln = c->lanes[i];
         HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        c->nstreams++;
         // Side streams only while every stream still has a hardware queue of its own (GPU_MAX_HW_QUEUES,
         // 4 by default): streams beyond that share queues, and two lanes whose replay kernels wait
         // (in-kernel flags) on generator kernels queued behind each other would never finish.  A lane
         // without a side stream runs its side work in stream order (and its QR iteration solo).
         // (Measured: side streams / teams on the other lanes as well slow the critical lane down more than
         // they speed those lanes up - C2 182 ms instead of 175 - so they are opt-in: KBDM_SIDE_ALL=1.)
-        if (i == 0 || (side_all && c->nlanes + i + 1 <= hwq)) HIPCHK(hipStreamCreateWithFlags(&ln.stream2, hipStreamNonBlocking));
-        else ln.stream2 = ln.stream;
+        if (i == 0 || (side_all && c->nlanes + i + 1 <= hwq)) {
+            HIPCHK(hipStreamCreateWithFlags(&ln.stream2, hipStreamNonBlocking));
+            c->nstreams++;
+        } else ln.stream2 = ln.stream;
         HIPCHK(hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
     }
     c->stream = c->lanes[0].stream;
+    // The in-kernel hand-off between the bidiagonal QR generator (side stream) and the rotation replay (main stream)
+    // needs both kernels resident at once, i.e. a hardware queue per stream.  The runtime reads GPU_MAX_HW_QUEUES
+    // when HIP is initialised (4 without it); streams beyond that share queues.  If this process's streams - those
+    // of every context of this library - no longer fit, this context's replay waits on a stream dependency instead
+    // (slower by the overlap, never wrong).  A host that initialised HIP before setting the variable gets the same
+    // conservative mode through KBDM_BDSQR_FLAG=0 or kbdm_plan_set_mode.
+    if (g_streams.fetch_add(c->nstreams) + c->nstreams > hwq) c->safe_replay = 1;
     HIPCHK(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
     c->nt_fac = env_int("KBDM_NT_FAC", c->nt_fac);
     c->nt_bdsqr = env_int("KBDM_NT_BDSQR", c->nt_bdsqr);
@@ -728,6 +753,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
 
 int kbdm_ctx_destroy(kbdm_ctx* ctx) {
     if (!ctx) return KBDM_OK;
+    g_streams.fetch_sub(ctx->nstreams);
     for (int i = 0; i < KB_MAX_LANES; ++i) {
         Lane& ln = ctx->lanes[i];
         if (ln.stream2 && ln.stream2 != ln.stream) hipStreamDestroy(ln.stream2);
@@ -763,6 +789,8 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
     hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork); hipFree(pl->d_rot); hipFree(pl->d_hdr);
     hipFree(pl->d_team); hipFree(pl->d_rings);
+    if (pl->h_signals) hipHostFree(pl->h_signals);
+    if (pl->h_out) hipHostFree(pl->h_out);
     for (auto& ch : pl->chunks)
         for (auto& e : ch.ev) hipEventDestroy(e);
     delete pl;
@@ -872,6 +900,103 @@ int kbdm_plan_download(kbdm_plan* pl, double* lines, double* sv, double* mu, uin
     if (keep && pl->total_lines) HIPCHK(hipMemcpyAsync(keep, pl->d_keep, pl->total_lines, hipMemcpyDeviceToHost, st));
     if (status && pl->B) HIPCHK(hipMemcpyAsync(status, pl->d_status, sizeof(int) * pl->B, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (status) {
+        const int force = env_int("KBDM_DEBUG_FORCE_STATUS", 0);      // test hook: pretend the members failed
+        if (force) for (int i = 0; i < pl->B; ++i) status[i] |= force;
+    }
+    return KBDM_OK;
+}
+
+int kbdm_plan_set_mode(kbdm_plan* pl, int mode) {
+    if (!pl || (mode & ~(KBDM_MODE_SAFE_REPLAY | KBDM_MODE_SOLO_QR))) return fail(KBDM_E_INVALID, "bad mode");
+    pl->mode = mode;
+    return KBDM_OK;
+}
+
+int kbdm_ctx_safe_replay(const kbdm_ctx* ctx) { return ctx ? ctx->safe_replay : 0; }
+
+int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l) {
+    if (B < 0 || (B > 0 && !m)) return -1;
+    // what plan_alloc asks hipMalloc for, before chunking: the matrix arena + rotation log dominate
+    double tot = 0.0;
+    for (int i = 0; i < B; ++i) {
+        const int li = l ? l[i] : m[i];
+        tot += (double)item_arena_elems(m[i], li) * sizeof(cd) + 9.0 * 8.0 * (m[i] + 2) + 64.0 * li + 8.0 * m[i] +
+               (double)KB_TEAM_SLOTS * 4096.0 + 512.0;
+    }
+    return (int64_t)tot;
+}
+
+int64_t kbdm_plan_workspace_bytes(const kbdm_plan* pl) {
+    if (!pl) return 0;
+    return (int64_t)(sizeof(cd) * pl->arena_elems + sizeof(double) * pl->varena_elems + sizeof(Rot) * pl->rot_elems +
+                     sizeof(RotBatch) * pl->hdr_elems + 57 * (size_t)pl->total_lines + 8 * (size_t)pl->total_sv +
+                     (size_t)pl->B * (sizeof(KbItem) + sizeof(TeamCtl) + 24) + sizeof(cd) * (size_t)pl->S * pl->N);
+}
+
+namespace {
+// layout of the pinned output block of kbdm_plan_submit: lines | sv | mu | status | keep
+struct OutLayout { size_t lines, sv, mu, status, keep, total; };
+OutLayout out_layout(const kbdm_plan* pl) {
+    OutLayout o;
+    o.lines = 0;
+    o.sv = o.lines + 32 * (size_t)pl->total_lines;
+    o.mu = o.sv + 8 * (size_t)pl->total_sv;
+    o.status = o.mu + 16 * (size_t)pl->total_lines;
+    o.keep = o.status + 4 * (size_t)pl->B;
+    o.total = ((o.keep + (size_t)pl->total_lines + 63) & ~(size_t)63) + 64;
+    return o;
+}
+}  // namespace
+
+int kbdm_plan_submit(kbdm_plan* pl, const double* signals_host) {
+    if (!pl) return fail(KBDM_E_INVALID, "null plan");
+    hipStream_t st = pl->ctx->stream;
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    const OutLayout o = out_layout(pl);
+    const size_t sig_bytes = sizeof(cd) * (size_t)pl->S * pl->N;
+    if (!pl->h_out) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&pl->h_out), o.total, hipHostMallocDefault));
+        pl->h_out_bytes = o.total;
+        if (sig_bytes) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&pl->h_signals), sig_bytes, hipHostMallocDefault));
+    }
+    if (pl->submitted) HIPCHK(hipStreamSynchronize(st));      // the staging buffers are still the previous run's
+    if (signals_host) {
+        if (!pl->d_signals) return fail(KBDM_E_INVALID, "the plan has no signals");
+        memcpy(pl->h_signals, signals_host, sig_bytes);
+        HIPCHK(hipMemcpyAsync(pl->d_signals, pl->h_signals, sig_bytes, hipMemcpyHostToDevice, st));
+    }
+    int r = kbdm_plan_execute(pl);
+    if (r) return r;
+    char* h = pl->h_out;
+    if (pl->total_lines) {
+        HIPCHK(hipMemcpyAsync(h + o.lines, pl->d_lines, 32 * (size_t)pl->total_lines, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h + o.mu, pl->d_mu, 16 * (size_t)pl->total_lines, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h + o.keep, pl->d_keep, (size_t)pl->total_lines, hipMemcpyDeviceToHost, st));
+    }
+    if (pl->total_sv) HIPCHK(hipMemcpyAsync(h + o.sv, pl->d_sv, 8 * (size_t)pl->total_sv, hipMemcpyDeviceToHost, st));
+    if (pl->B) HIPCHK(hipMemcpyAsync(h + o.status, pl->d_status, 4 * (size_t)pl->B, hipMemcpyDeviceToHost, st));
+    pl->submitted = true;
+    return KBDM_OK;
+}
+
+int kbdm_plan_collect(kbdm_plan* pl, double* lines, double* sv, double* mu, uint8_t* keep, int32_t* status) {
+    if (!pl) return fail(KBDM_E_INVALID, "null plan");
+    if (!pl->submitted) return fail(KBDM_E_INVALID, "kbdm_plan_collect without kbdm_plan_submit");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->ctx->stream));
+    pl->submitted = false;
+    const OutLayout o = out_layout(pl);
+    const char* h = pl->h_out;
+    if (lines) memcpy(lines, h + o.lines, 32 * (size_t)pl->total_lines);
+    if (sv) memcpy(sv, h + o.sv, 8 * (size_t)pl->total_sv);
+    if (mu) memcpy(mu, h + o.mu, 16 * (size_t)pl->total_lines);
+    if (keep) memcpy(keep, h + o.keep, (size_t)pl->total_lines);
+    if (status) {
+        memcpy(status, h + o.status, 4 * (size_t)pl->B);
+        const int force = env_int("KBDM_DEBUG_FORCE_STATUS", 0);      // test hook: pretend the members failed
+        if (force) for (int i = 0; i < pl->B; ++i) status[i] |= force;
+    }
     return KBDM_OK;
 }
 
@@ -1018,12 +1143,16 @@ int kbdm_plan_gather(kbdm_plan* pl, int world, int rank, const int64_t* bytes, i
     } else {
         // ONE grouped operation: every block travels once, straight between device buffers
         NCCLCHK(g_rccl.GroupStart());
-        for (int r = 0; r < world; ++r) {
+        int err = 0;                              // the group is closed on every path out of here
+        for (int r = 0; r < world && !err; ++r) {
             const bool to_r = root < 0 || r == root;
-            if (to_r && mine) NCCLCHK(g_rccl.Send(ctx->d_pack, (size_t)mine, kNcclUint8, r, ctx->comm, st));
-            if (receive && bytes[r]) NCCLCHK(g_rccl.Recv(ctx->d_gather + off[r], (size_t)bytes[r], kNcclUint8, r, ctx->comm, st));
+            if (to_r && mine) err = g_rccl.Send(ctx->d_pack, (size_t)mine, kNcclUint8, r, ctx->comm, st);
+            if (!err && receive && bytes[r])
+                err = g_rccl.Recv(ctx->d_gather + off[r], (size_t)bytes[r], kNcclUint8, r, ctx->comm, st);
         }
-        NCCLCHK(g_rccl.GroupEnd());
+        const int end = g_rccl.GroupEnd();
+        NCCLCHK(err);
+        NCCLCHK(end);
     }
     if (host_out && receive && total) HIPCHK(hipMemcpyAsync(host_out, ctx->d_gather, total, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

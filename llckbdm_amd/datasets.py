@@ -49,7 +49,7 @@ def config2(seed=0):
 
 def north_star(seed=0, step=2):
     """The ensemble BASELINE.json's north_star quotes its target on: N=2048, 16 peaks, sigma=1e-3,
-    m = 100..500 (step 2: 201 members; the sum of m^3 is 1.84 x that of C2)."""
+    m = 100..500 (step 2: 201 members; the sum of m^3 is 2.44 x that of C2: 7.86e9 against 3.22e9)."""
     sig = add_noise(brain_sim_signal(2048), 1e-3, seed)
     m = np.arange(100, 501, step, dtype=np.int32)
     return sig.reshape(1, -1), np.zeros(len(m), dtype=np.int32), m

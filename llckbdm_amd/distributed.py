@@ -4,9 +4,12 @@ Ensemble members are independent (reference sampling.py:52-62 has no loop-carrie
 no data-path collective until the end: ONE variable-length gather of every rank's packed results.  Every rank
 derives the same member -> rank table (`shard_items`, deterministic), hence the size of every rank's block: no
 size exchange.  In the product the gather is `kbdm_plan_gather` of the C ABI (RCCL over xGMI, bound by the library
-itself, device buffers to device buffers: `RcclComm`); the CPU tests run the same code over gloo (`GlooComm`).
-A process launcher is only needed to start the ranks and to hand rank 0's communicator id to the others.
+itself, device buffers to device buffers: `RcclComm`); the CPU tests run the same sharding / packing / unpacking code
+with the transport swapped (`HostComm` over `launch.Rendezvous`, standard library only).  A process launcher is only
+needed to start the ranks and to hand rank 0's communicator id to the others (`llckbdm_amd.launch`).
 """
+import warnings
+
 import numpy as np
 
 from . import _lib
@@ -69,10 +72,12 @@ class RcclComm:
     """The product's communicator: RCCL inside libkbdm_hip.so, owned by the engine's context.
 
     ``exchange_id(id_or_None) -> id`` is the launcher's job: it must return rank 0's 128-byte id on every rank
-    (rank 0 passes the id it created, the others pass None).  Nothing else crosses Python."""
+    (rank 0 passes the id it created, the others pass None): `launch.Rendezvous.exchange_id`.  Nothing else crosses
+    Python."""
 
-    def __init__(self, engine, world, rank, exchange_id, force=False):
+    def __init__(self, engine, world, rank, exchange_id, force=False, ctx=None):
         self.engine, self.world, self.rank = engine, int(world), int(rank)
+        self.ctx = engine.ctx if ctx is None else ctx
         lib = engine.lib
         self.owns = self.world > 1 or force         # force: a one-rank communicator (rehearsal of the RCCL path)
         if self.owns:
@@ -83,16 +88,25 @@ class RcclComm:
                 uid = buf.tobytes()
             uid = exchange_id(uid)
             buf = np.frombuffer(uid, dtype=np.uint8).copy()
-            _lib.check(lib.kbdm_comm_init(engine.ctx, self.world, self.rank, _lib.ptr(buf)))
+            _lib.check(lib.kbdm_comm_init(self.ctx, self.world, self.rank, _lib.ptr(buf)))
 
-    def solve_and_gather(self, signals, ms, ls, p, q, dwell, sizes, root=-1):
+    def solve_and_gather(self, signals, sig_idx, ms, ls, p, q, dwell, sizes, root=-1):
         """Solve this rank's members and gather every rank's packed block (`sizes[r]` bytes each) on the device;
-        returns the concatenated host copy on receiving ranks (None elsewhere)."""
+        returns the concatenated host copy on receiving ranks (None elsewhere).  A rank whose members report
+        non-convergence runs its share once more in the conservative modes before the gather (the same single retry
+        as `engine.checked`), so the status words that travel are final."""
         eng = self.engine
-        n = len(ms)
-        plan = eng.cached_plan(signals.shape[0], signals.shape[1], np.zeros(n, dtype=np.int32), ms, ls, p, q, dwell)
+        plan = eng.cached_plan(signals.shape[0], signals.shape[1], sig_idx, ms, ls, p, q, dwell)
         plan.upload(signals)
-        plan.execute(sync=False)
+        plan.execute(sync=True)
+        if len(ms):
+            status = plan.download_status()
+            if np.any(status & (_lib.STAT_SVD_NOCONV | _lib.STAT_EIG_NOCONV)):
+                plan.set_mode(_lib.MODE_SAFE_REPLAY | _lib.MODE_SOLO_QR)
+                try:
+                    plan.execute(sync=True)
+                finally:
+                    plan.set_mode(0)
         return self.gather_plan(plan, sizes, root)
 
     def gather_plan(self, plan, sizes, root=-1):
@@ -105,78 +119,99 @@ class RcclComm:
 
     def close(self):
         if self.owns:
-            self.engine.lib.kbdm_comm_destroy(self.engine.ctx)
+            self.engine.lib.kbdm_comm_destroy(self.ctx)
             self.owns = False
 
 
-class GlooComm:
-    """CPU stand-in with the same interface (tests): the per-rank solver is injected, the blocks are packed on the
-    host in the library's layout and all-gathered over a torch.distributed (gloo) group."""
+class HostComm:
+    """CPU stand-in with the same interface (tests): the per-rank solver is injected (`solve(signals, sig_idx, m, l,
+    p=, q=, dwell=) -> BatchResult`), the blocks are packed on the host in the library's layout - status words
+    included - and all-gathered through `launch.Rendezvous` (one TCP socket per rank, standard library only)."""
 
-    def __init__(self, solve, group=None):
-        import torch.distributed as dist
-        self.solve, self.group = solve, group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+    def __init__(self, solve, rdzv):
+        self.solve, self.rdzv = solve, rdzv
+        self.world, self.rank = rdzv.world, rdzv.rank
 
-    def solve_and_gather(self, signals, ms, ls, p, q, dwell, sizes, root=-1):
-        import torch
-        import torch.distributed as dist
+    def solve_and_gather(self, signals, sig_idx, ms, ls, p, q, dwell, sizes, root=-1):
         n = len(ms)
         if n:
-            res = self.solve(signals, np.zeros(n, dtype=np.int32), list(ms), list(ls), p=p, q=q, dwell=dwell)
+            res = self.solve(signals, np.asarray(sig_idx, dtype=np.int32), list(ms), list(ls), p=p, q=q, dwell=dwell)
             lines = np.concatenate([np.asarray(res.line_list(k)).reshape(-1, 4) for k in range(n)])
             keep = np.concatenate([np.asarray(res.keep_mask(k)) for k in range(n)])
             svs = np.concatenate([np.asarray(res.singular_values(k)) for k in range(n)])
-            block = pack_block(lines, svs, np.zeros(n, np.int32), keep)
+            status = np.zeros(n, np.int32) if getattr(res, "status", None) is None else np.asarray(res.status, np.int32)
+            block = pack_block(lines, svs, status, keep)
         else:
             block = pack_block(np.zeros((0, 4)), np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.uint8))
         assert block.size == sizes[self.rank], (block.size, sizes[self.rank])
-        pad = int(max(max(sizes), 16))
-        mine = torch.zeros(pad, dtype=torch.uint8)
-        mine[:block.size] = torch.from_numpy(block)
-        parts = [torch.zeros(pad, dtype=torch.uint8) for _ in range(self.world)]
-        dist.all_gather(parts, mine, group=self.group)
-        return np.concatenate([parts[r][:int(sizes[r])].numpy() for r in range(self.world)])
+        parts = self.rdzv.allgather(block.tobytes())
+        if root >= 0 and root != self.rank:
+            return None
+        return np.concatenate([np.frombuffer(b, dtype=np.uint8) for b in parts])
 
     def close(self):
         pass
 
 
-def sample_kbdm_sharded(data, dwell, m_range, p, l, q=0, filter_invalid_features=True, comm=None, root=-1):
-    """Distributed drop-in for ``sample_kbdm`` (reference sampling.py:8-72): every rank solves its share of
-    ``m_range`` and the receiving ranks (all of them unless ``root`` names one) get the complete
-    ``(line_lists, infos)`` in ``m_range`` order; the other ranks get ``(None, None)``.
+def sample_kbdm_signals_sharded(signals, dwell, sig_idx, m_list, p=1, l=None, q=0, filter_invalid_features=True,
+                                comm=None, root=-1):
+    """Distributed form of `sampling.sample_kbdm_signals` (the loop sampling.py:52-62 over a grid of signals, e.g.
+    the 64 voxels x 256 members of a multi-voxel MRSI grid): item i = (signals[sig_idx[i]], m_list[i]).  The items
+    are dealt over the ranks by LPT on m^3 (every rank derives the same table); every rank uploads only the signals
+    its items use.  Receiving ranks (all unless `root` names one) get ``(line_lists, infos, item_index)`` of the
+    non-empty members in item order; the others ``(None, None, None)``.  Members whose status word still reports
+    non-convergence after the per-rank retry raise numpy.linalg.LinAlgError on every receiving rank.
 
-    ``comm``: an `RcclComm` (product) or `GlooComm` (CPU tests)."""
+    ``comm``: an `RcclComm` (product) or `HostComm` (CPU tests)."""
     if comm is None:
-        raise ValueError("sample_kbdm_sharded needs a communicator (RcclComm / GlooComm)")
-    data = np.asarray(data)
+        raise ValueError("the sharded samplers need a communicator (RcclComm / HostComm)")
+    signals = np.atleast_2d(np.asarray(signals))
     ms, ls = [], []
-    for m in m_range:
-        mm, ll = _resolve_m_l(data.size, m, p, l)
+    for m in m_list:
+        mm, ll = _resolve_m_l(signals.shape[1], m, p, l)
         ms.append(mm)
         ls.append(ll)
     ms, ls = np.asarray(ms, dtype=np.int32), np.asarray(ls, dtype=np.int32)
+    sig_idx = np.asarray(sig_idx, dtype=np.int32)
     world, rank = comm.world, comm.rank
     parts = shard_items(ms.astype(np.float64) ** 3, world)
     sizes = np.array([packed_bytes(ls[idx].sum(), ms[idx].sum(), len(idx)) for idx in parts], dtype=np.int64)
     mine = parts[rank]
-    buf = comm.solve_and_gather(np.ascontiguousarray(data, dtype=np.complex128).reshape(1, -1), ms[mine], ls[mine],
-                                p, q, dwell, sizes, root)
+    used = np.unique(sig_idx[mine]) if len(mine) else np.zeros(1, dtype=np.int32)
+    remap = np.zeros(signals.shape[0], dtype=np.int32)
+    remap[used] = np.arange(len(used), dtype=np.int32)
+    buf = comm.solve_and_gather(np.ascontiguousarray(signals[used], dtype=np.complex128), remap[sig_idx[mine]],
+                                ms[mine], ls[mine], p, q, dwell, sizes, root)
     if buf is None:
-        return None, None
-    return unpack_gathered(buf, parts, sizes, ms, ls, p, q, filter_invalid_features)
+        return None, None, None
+    return unpack_gathered(buf, parts, sizes, ms, ls, p, q, filter_invalid_features, with_index=True)
 
 
-def unpack_gathered(buf, parts, sizes, ms, ls, p, q, filter_invalid_features=True):
+def sample_kbdm_sharded(data, dwell, m_range, p, l, q=0, filter_invalid_features=True, comm=None, root=-1):
+    """Distributed drop-in for ``sample_kbdm`` (reference sampling.py:8-72): every rank solves its share of
+    ``m_range`` and the receiving ranks (all of them unless ``root`` names one) get the complete
+    ``(line_lists, infos)`` in ``m_range`` order; the other ranks get ``(None, None)``."""
+    data = np.asarray(data)
+    m_list = list(m_range)
+    out = sample_kbdm_signals_sharded(data.reshape(1, -1), dwell, np.zeros(len(m_list), dtype=np.int32), m_list, p=p, l=l,
+                                      q=q, filter_invalid_features=filter_invalid_features, comm=comm, root=root)
+    return out[0], out[1]
+
+
+def unpack_gathered(buf, parts, sizes, ms, ls, p, q, filter_invalid_features=True, with_index=False):
     """Gathered blocks (rank order) -> (line_lists, infos) in member order, empty results dropped
-    (reference sampling.py:64-70)."""
+    (reference sampling.py:64-70).  The status words travel with the blocks: SVD_NOCONV / EIG_NOCONV raise
+    numpy.linalg.LinAlgError (what scipy.linalg.svd / eig do inside the reference's kbdm(): kbdm.py:166,192),
+    INVIT_WEAK warns."""
+    from .engine import KbdmAccuracyWarning
     line_lists, infos = [None] * len(ms), [None] * len(ms)
+    status = np.zeros(len(ms), dtype=np.int32)
     off = 0
     for r, idx in enumerate(parts):
         nl, nsv = int(ls[idx].sum()), int(ms[idx].sum())
-        rl, rs, _, rk = unpack_block(buf[off:off + int(sizes[r])], nl, nsv, len(idx))
+        rl, rs, rst, rk = unpack_block(buf[off:off + int(sizes[r])], nl, nsv, len(idx))
         off += int(sizes[r])
+        status[idx] = rst
         o = so = 0
         for i in idx:
             li, mi = int(ls[i]), int(ms[i])
@@ -187,9 +222,18 @@ def unpack_gathered(buf, parts, sizes, ms, ls, p, q, filter_invalid_features=Tru
             infos[i] = KbdmInfo(m=mi, l=li, p=p, q=q, singular_values=rs[so:so + mi].copy())
             o += li
             so += mi
-    out_l, out_i = [], []
-    for ll_i, info in zip(line_lists, infos):
+    hard = np.nonzero(status & (_lib.STAT_SVD_NOCONV | _lib.STAT_EIG_NOCONV))[0]
+    if len(hard):
+        raise np.linalg.LinAlgError("sharded KBDM ensemble: SVD / eig did not converge for member(s) %s (m = %s, status %s)"
+                                    % ([int(i) for i in hard], [int(ms[i]) for i in hard], [int(status[i]) for i in hard]))
+    weak = np.nonzero(status & _lib.STAT_INVIT_WEAK)[0]
+    if len(weak):
+        warnings.warn(f"sharded KBDM ensemble: inverse iteration was weak for member(s) {[int(i) for i in weak]}",
+                      KbdmAccuracyWarning, stacklevel=2)
+    out_l, out_i, out_x = [], [], []
+    for i, (ll_i, info) in enumerate(zip(line_lists, infos)):
         if len(ll_i) > 0:                      # reference sampling.py:67-70
             out_l.append(ll_i)
             out_i.append(info)
-    return out_l, out_i
+            out_x.append(i)
+    return (out_l, out_i, out_x) if with_index else (out_l, out_i)

@@ -2,9 +2,16 @@
 
 This is the host half of the batched replacement for the reference's serial loop
 ``for m in m_range: kbdm(...)`` (llckbdm/sampling.py:52-70).
+
+`Engine.solve` runs one batch; `Engine.submit` / `Pending.result` keep up to `in_flight` independent batches on the
+GPU at once (each on a context of its own: three HIP streams), which is how the throughput-bound stages of one
+ensemble run underneath the latency-bound QR iterations of another.  Results carry the solver's per-member status
+word; `checked` turns it into what the reference's LAPACK calls do on failure (scipy.linalg.svd / eig raise
+LinAlgError: llckbdm/kbdm.py:166,192) after ONE conservative retry of the flagged members.
 """
 import os
 import threading
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -13,6 +20,11 @@ from . import _lib
 
 _default = None
 _default_lock = threading.Lock()
+
+
+class KbdmAccuracyWarning(UserWarning):
+    """A member's eigenvectors came from an inverse iteration that did not reach its growth bound
+    (status bit INVIT_WEAK): its lines may be less accurate than 1e-8."""
 
 
 class BatchResult:
@@ -38,19 +50,62 @@ class BatchResult:
         return self.mu[self.line_off[i]:self.line_off[i + 1]]
 
 
+def checked(engine, res, signals, sig_idx, m, l, p, q, dwell, what="KBDM"):
+    """The status word as the drop-in contract: members flagged SVD_NOCONV / EIG_NOCONV are solved ONCE more in the
+    conservative modes (stream-dependency replay, solo QR iteration; same process) and patched into `res`; members
+    that are still flagged raise numpy.linalg.LinAlgError as scipy.linalg.svd / scipy.linalg.eig do in the reference
+    (kbdm.py:166,192); INVIT_WEAK warns.  Returns `res`."""
+    hard = _lib.STAT_SVD_NOCONV | _lib.STAT_EIG_NOCONV
+    bad = np.nonzero(res.status & hard)[0]
+    if len(bad):
+        m = np.asarray(m, dtype=np.int32)
+        l = np.asarray(l, dtype=np.int32)
+        sig_idx = np.asarray(sig_idx, dtype=np.int32)
+        signals = np.ascontiguousarray(np.atleast_2d(signals), dtype=np.complex128)
+        plan = engine.plan(signals.shape[0], signals.shape[1], sig_idx[bad], m[bad], l[bad], p, q, dwell)
+        try:
+            plan.set_mode(_lib.MODE_SAFE_REPLAY | _lib.MODE_SOLO_QR)
+            plan.submit(signals)
+            again = plan.collect()
+        finally:
+            plan.close()
+        for k, i in enumerate(bad):
+            res.lines[res.line_off[i]:res.line_off[i + 1]] = again.line_list(k)
+            res.mu[res.line_off[i]:res.line_off[i + 1]] = again.eigenvalues(k)
+            res.keep[res.line_off[i]:res.line_off[i + 1]] = again.keep[again.line_off[k]:again.line_off[k + 1]]
+            res.sv[res.sv_off[i]:res.sv_off[i + 1]] = again.singular_values(k)
+            res.status[i] = again.status[k]
+        still = np.nonzero(res.status & hard)[0]
+        if len(still):
+            svd = [int(i) for i in still if res.status[i] & _lib.STAT_SVD_NOCONV]
+            eig = [int(i) for i in still if res.status[i] & _lib.STAT_EIG_NOCONV]
+            parts = []
+            if svd:
+                parts.append("SVD did not converge for member(s) %s (m = %s)" % (svd, [int(m[i]) for i in svd]))
+            if eig:
+                parts.append("eig algorithm did not converge for member(s) %s (l = %s)" % (eig, [int(l[i]) for i in eig]))
+            raise np.linalg.LinAlgError(f"{what}: " + "; ".join(parts))
+    weak = np.nonzero(res.status & _lib.STAT_INVIT_WEAK)[0]
+    if len(weak):
+        warnings.warn(f"{what}: inverse iteration was weak for member(s) {[int(i) for i in weak]}: their lines may be "
+                      "less accurate than 1e-8", KbdmAccuracyWarning, stacklevel=3)
+    return res
+
+
 class Plan:
     """A fixed batch geometry with its device workspace (kbdm_plan in include/kbdm_hip.h)."""
 
-    def __init__(self, engine, S, N, sig_idx, m, l, p, q, dwell):
+    def __init__(self, engine, S, N, sig_idx, m, l, p, q, dwell, ctx=None):
         self.engine = engine
         lib = engine.lib
+        ctx = engine.ctx if ctx is None else ctx
         self.S, self.N, self.B = int(S), int(N), len(m)
         self.sig_idx = np.ascontiguousarray(sig_idx, dtype=np.int32)
         self.m = np.ascontiguousarray(m, dtype=np.int32)
         self.l = np.ascontiguousarray(l, dtype=np.int32)
         self.p, self.q, self.dwell = int(p), float(q), float(dwell)
         h = _lib.c_void_p()
-        _lib.check(lib.kbdm_plan_create(engine.ctx, self.S, self.N, self.B, _lib.ptr(self.sig_idx),
+        _lib.check(lib.kbdm_plan_create(ctx, self.S, self.N, self.B, _lib.ptr(self.sig_idx),
                                         _lib.ptr(self.m), _lib.ptr(self.l), self.p, self.q, self.dwell, h))
         self.handle = h
         self.line_off = np.zeros(self.B + 1, dtype=np.int64)
@@ -77,6 +132,31 @@ class Plan:
         names = [lib.kbdm_stage_name(i).decode() for i in range(_lib.KBDM_NSTAGES)]
         _lib.check(lib.kbdm_plan_wait_stage(self.handle, names.index(name)))
 
+    def set_mode(self, mode):
+        """Conservative execution modes (`_lib.MODE_*`, include/kbdm_hip.h KBDM_MODE_*)."""
+        _lib.check(self.engine.lib.kbdm_plan_set_mode(self.handle, int(mode)))
+
+    def workspace_bytes(self):
+        return int(self.engine.lib.kbdm_plan_workspace_bytes(self.handle))
+
+    def submit(self, signals=None):
+        """Host -> host without blocking: stage the signals (None = keep the uploaded ones), enqueue H2D, the
+        pipeline and the D2H of every output; `collect` waits and returns the BatchResult."""
+        sig = None
+        if signals is not None:
+            sig = np.ascontiguousarray(signals, dtype=np.complex128).reshape(self.S, self.N)
+        _lib.check(self.engine.lib.kbdm_plan_submit(self.handle, _lib.ptr(sig)))
+
+    def collect(self):
+        lines = np.empty((self.total_lines, 4), dtype=np.float64)
+        sv = np.empty(self.total_sv, dtype=np.float64)
+        mu = np.empty(self.total_lines, dtype=np.complex128)
+        keep = np.empty(self.total_lines, dtype=np.uint8)
+        status = np.empty(self.B, dtype=np.int32)
+        _lib.check(self.engine.lib.kbdm_plan_collect(self.handle, _lib.ptr(lines), _lib.ptr(sv), _lib.ptr(mu),
+                                                     _lib.ptr(keep), _lib.ptr(status)))
+        return BatchResult(lines, sv, mu, keep, status, self.line_off, self.sv_off)
+
     def download(self):
         lines = np.empty((self.total_lines, 4), dtype=np.float64)
         sv = np.empty(self.total_sv, dtype=np.float64)
@@ -86,6 +166,12 @@ class Plan:
         _lib.check(self.engine.lib.kbdm_plan_download(self.handle, _lib.ptr(lines), _lib.ptr(sv), _lib.ptr(mu),
                                                       _lib.ptr(keep), _lib.ptr(status)))
         return BatchResult(lines, sv, mu, keep, status, self.line_off, self.sv_off)
+
+    def download_status(self):
+        """The per-member status words alone (waits for the plan)."""
+        status = np.empty(self.B, dtype=np.int32)
+        _lib.check(self.engine.lib.kbdm_plan_download(self.handle, None, None, None, None, _lib.ptr(status)))
+        return status
 
     def stage_ms(self):
         ms = np.zeros(_lib.KBDM_NSTAGES, dtype=np.float32)
@@ -116,10 +202,53 @@ class Plan:
             pass
 
 
-class Engine:
-    """One GPU context (kbdm_ctx).  One per process and device."""
+class Pending:
+    """A batch in flight (`Engine.submit`)."""
 
-    def __init__(self, device=None):
+    def __init__(self, engine, slot, plan, args):
+        self._engine, self._slot, self._plan, self._args = engine, slot, plan, args
+        self.plan = plan                   # stays valid (stage timers, device results) until its context runs again
+        self._res = None
+
+    def _finish(self):
+        if self._res is None:
+            self._res = self._plan.collect()
+            self._slot.pending = None
+            self._plan = None
+        return self._res
+
+    def wait(self):
+        """Wait for the batch without copying anything out of the staging buffers yet."""
+        self.plan.sync()
+
+    def result(self, check=True):
+        """Wait for the batch; `check` applies the status contract (`checked`: retry once, then LinAlgError)."""
+        with self._engine._lock:
+            res = self._finish()
+            if check and self._args is not None:
+                args, self._args = self._args, None
+                checked(self._engine, res, *args)
+            return res
+
+
+class _Slot:
+    """One context (kbdm_ctx: two lanes + a side stream) with the plans it has cached."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.plans = OrderedDict()
+        self.pending = None
+        self.seq = 0
+
+
+class Engine:
+    """One GPU.  Owns up to `in_flight` contexts (kbdm_ctx, created on demand) so that independent batches overlap."""
+
+    # the second / third batch of a burst starts when the one before it has reached this stage: pipelines with the
+    # same cycle keep the phase they start in, and started together they meet panels against panels
+    STAGGER_STAGE = {2: "k_hess", 3: "k_bdsqr_sort"}
+
+    def __init__(self, device=None, in_flight=None):
         self.lib = _lib.load()
         if device is None:
             device = int(os.environ.get("KBDM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
@@ -128,50 +257,160 @@ class Engine:
             raise _lib.KbdmHipError("no HIP device visible: llckbdm_amd needs an MI355X (gfx950); "
                                     "there is no CPU fallback")
         self.device = int(device) % n
+        self.in_flight = max(1, int(os.environ.get("KBDM_IN_FLIGHT", "3") if in_flight is None else in_flight))
+        self._lock = threading.RLock()
+        self._slots = [_Slot(self._new_ctx())]
+        self.ctx = self._slots[0].ctx
+        self._seq = 0
+        self._burst = 0
+        self._last = None
+        self.stagger = os.environ.get("KBDM_STAGGER", "1") != "0"
+        # Plans of recent batches, keyed on the batch geometry: a plan owns its device workspace (about 1 GB for a C2
+        # ensemble, up to the 96 GiB workspace budget for a C4-sized one), and callers such as `sample_kbdm` /
+        # `iterative_llc_kbdm` solve the same geometry again and again with new signals.  The cache is bounded by
+        # BYTES over all contexts; idle plans are evicted (least recently used first) BEFORE a new one is allocated.
+        self.plan_cache_bytes = int(float(os.environ.get("KBDM_PLAN_CACHE_GIB", "150")) * 2 ** 30)
+        self.plan_cache_size = int(os.environ.get("KBDM_PLAN_CACHE", "4"))       # plans per context
+
+    def _new_ctx(self):
         h = _lib.c_void_p()
         _lib.check(self.lib.kbdm_ctx_create(self.device, h))
-        self.ctx = h
-        # plans of recent `solve` calls, keyed on the batch geometry: a plan owns its device workspace (about 1 GB
-        # for a C2 ensemble), and callers such as `sample_kbdm` / `iterative_llc_kbdm` solve the same geometry
-        # again and again with new signals
-        self._plan_cache = OrderedDict()
-        self.plan_cache_size = int(os.environ.get("KBDM_PLAN_CACHE", "4"))
+        return h
 
-    def plan(self, S, N, sig_idx, m, l, p=1, q=0.0, dwell=1.0):
-        return Plan(self, S, N, sig_idx, m, l, p, q, dwell)
+    def plan(self, S, N, sig_idx, m, l, p=1, q=0.0, dwell=1.0, ctx=None):
+        return Plan(self, S, N, sig_idx, m, l, p, q, dwell, ctx=ctx)
 
-    def cached_plan(self, S, N, sig_idx, m, l, p=1, q=0.0, dwell=1.0):
-        """The plan for this batch geometry, created on first use and kept (LRU, `plan_cache_size` entries)."""
-        sig_idx = np.ascontiguousarray(sig_idx, dtype=np.int32)
-        m = np.ascontiguousarray(m, dtype=np.int32)
-        l = np.ascontiguousarray(l, dtype=np.int32)
-        key = (int(S), int(N), sig_idx.tobytes(), m.tobytes(), l.tobytes(), int(p), float(q), float(dwell))
-        plan = self._plan_cache.get(key)
-        if plan is not None and plan.handle is not None:
-            self._plan_cache.move_to_end(key)
+    # ---- plan cache -------------------------------------------------------------------
+    def _held_bytes(self):
+        return sum(pl.workspace_bytes() for sl in self._slots for pl in sl.plans.values() if pl.handle is not None)
+
+    def _evict(self, need, keep_slot=None, everything=False):
+        """Close idle cached plans, least recently used first, until `need` more bytes fit the budget."""
+        cands = []
+        for sl in self._slots:
+            busy = sl.pending._plan if sl.pending is not None else None
+            for key, pl in sl.plans.items():
+                if pl is not busy:
+                    cands.append((getattr(pl, "_used", 0), sl, key, pl))
+        cands.sort(key=lambda c: c[0])
+        held = self._held_bytes()
+        for _, sl, key, pl in cands:
+            if not everything and held + need <= self.plan_cache_bytes:
+                break
+            held -= pl.workspace_bytes()
+            pl.close()
+            del sl.plans[key]
+
+    def cached_plan(self, S, N, sig_idx, m, l, p=1, q=0.0, dwell=1.0, slot=None):
+        """The plan for this batch geometry on context `slot` (default: the first), created on first use and kept."""
+        with self._lock:
+            sl = self._slots[0] if slot is None else slot
+            sig_idx = np.ascontiguousarray(sig_idx, dtype=np.int32)
+            m = np.ascontiguousarray(m, dtype=np.int32)
+            l = np.ascontiguousarray(l, dtype=np.int32)
+            key = (int(S), int(N), sig_idx.tobytes(), m.tobytes(), l.tobytes(), int(p), float(q), float(dwell))
+            plan = sl.plans.get(key)
+            self._seq += 1
+            if plan is not None and plan.handle is not None:
+                sl.plans.move_to_end(key)
+                plan._used = self._seq
+                return plan
+            est = int(self.lib.kbdm_workspace_estimate(len(m), _lib.ptr(m), _lib.ptr(l)))
+            est = min(est, int(float(os.environ.get("KBDM_WS_GIB", "96")) * 2 ** 30))
+            self._evict(est)
+            while len(sl.plans) >= max(1, self.plan_cache_size):
+                busy = sl.pending._plan if sl.pending is not None else None
+                k0 = next((k for k, pl in sl.plans.items() if pl is not busy), None)
+                if k0 is None:
+                    break
+                sl.plans.pop(k0).close()
+            try:
+                plan = self.plan(S, N, sig_idx, m, l, p, q, dwell, ctx=sl.ctx)
+            except _lib.KbdmHipError:
+                self._evict(0, everything=True)            # out of device memory: drop every idle plan, try once more
+                plan = self.plan(S, N, sig_idx, m, l, p, q, dwell, ctx=sl.ctx)
+            plan._used = self._seq
+            sl.plans[key] = plan
             return plan
-        plan = self.plan(S, N, sig_idx, m, l, p, q, dwell)
-        self._plan_cache[key] = plan
-        while len(self._plan_cache) > max(1, self.plan_cache_size):
-            _, old = self._plan_cache.popitem(last=False)
-            old.close()
-        return plan
 
     def clear_plan_cache(self):
-        for plan in self._plan_cache.values():
-            plan.close()
-        self._plan_cache.clear()
+        with self._lock:
+            self.drain()
+            for sl in self._slots:
+                for plan in sl.plans.values():
+                    plan.close()
+                sl.plans.clear()
 
-    def solve(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0):
-        """signals: (S, N) complex; items (sig_idx[i], m[i], l[i]).  Returns BatchResult.
-        The plan (device workspace) of a geometry is reused by later calls with the same geometry."""
-        signals = np.ascontiguousarray(np.atleast_2d(signals), dtype=np.complex128)
-        m = np.asarray(m, dtype=np.int32)
-        l = m.copy() if l is None else np.asarray(l, dtype=np.int32)
-        plan = self.cached_plan(signals.shape[0], signals.shape[1], sig_idx, m, l, p, q, dwell)
-        plan.upload(signals)
-        plan.execute()
-        return plan.download()
+    # ---- batches ----------------------------------------------------------------------
+    def _pick_slot(self, key_fn):
+        idle = [sl for sl in self._slots if sl.pending is None]
+        if not idle and len(self._slots) < self.in_flight:
+            self._slots.append(_Slot(self._new_ctx()))
+            idle = [self._slots[-1]]
+        if not idle:
+            oldest = min(self._slots, key=lambda sl: sl.seq)
+            oldest.pending._finish()
+            idle = [oldest]
+        for sl in idle:                       # an idle context that already holds this geometry's workspace
+            if key_fn(sl):
+                return sl
+        return idle[0]
+
+    def ensure_contexts(self, n=None):
+        """Create the contexts of the pool up front (they are otherwise created when first needed)."""
+        with self._lock:
+            while len(self._slots) < (self.in_flight if n is None else min(n, self.in_flight)):
+                self._slots.append(_Slot(self._new_ctx()))
+            return [sl.ctx for sl in self._slots]
+
+    def submit(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0, resident=False):
+        """Start one batch (host signals in, host results out) and return at once: a `Pending`.  Up to `in_flight`
+        batches run concurrently, each on its own context; a further submit first waits for the oldest one.
+        `resident`: skip the upload when the plan that takes the batch already holds exactly this `signals` object
+        (benchmarks with inputs resident in HBM)."""
+        with self._lock:
+            sig_obj = signals
+            signals = np.ascontiguousarray(np.atleast_2d(signals), dtype=np.complex128)
+            m = np.ascontiguousarray(m, dtype=np.int32)
+            l = m.copy() if l is None else np.ascontiguousarray(l, dtype=np.int32)
+            sig_idx = np.ascontiguousarray(sig_idx, dtype=np.int32)
+            S, N = signals.shape
+            key = (int(S), int(N), sig_idx.tobytes(), m.tobytes(), l.tobytes(), int(p), float(q), float(dwell))
+            if all(sl.pending is None for sl in self._slots):
+                self._burst = 0
+            sl = self._pick_slot(lambda s: key in s.plans and s.plans[key].handle is not None)
+            plan = self.cached_plan(S, N, sig_idx, m, l, p, q, dwell, slot=sl)
+            nfl = self.in_flight
+            if self.stagger and 1 <= self._burst < nfl and self._last is not None and self._last._plan is not None \
+                    and self._last._slot is not sl:
+                try:
+                    self._last._plan.wait_stage(self.STAGGER_STAGE.get(nfl, "k_svd_fac"))
+                except ValueError:
+                    pass
+            if resident and getattr(plan, "_sig_obj", None) is sig_obj:
+                plan.submit(None)
+            else:
+                plan.submit(signals)
+                plan._sig_obj = sig_obj if resident else None
+            self._seq += 1
+            sl.seq = self._seq
+            pend = Pending(self, sl, plan, (signals, sig_idx, m, l, p, q, dwell))
+            sl.pending = pend
+            self._last = pend
+            self._burst += 1
+            return pend
+
+    def drain(self):
+        """Wait for every batch in flight (their results stay with their `Pending`)."""
+        with self._lock:
+            for sl in self._slots:
+                if sl.pending is not None:
+                    sl.pending._finish()
+
+    def solve(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0, check=False):
+        """signals: (S, N) complex; items (sig_idx[i], m[i], l[i]).  Returns BatchResult (raw status word unless
+        `check`).  The plan (device workspace) of a geometry is reused by later calls with the same geometry."""
+        return self.submit(signals, sig_idx, m, l, p, q, dwell).result(check=check)
 
     # ---- stage entry points (parity tests) -------------------------------------------
     def hankel(self, signals, sig_idx, m, p):
@@ -263,7 +502,9 @@ class Engine:
     def close(self):
         if self.ctx is not None:
             self.clear_plan_cache()
-            self.lib.kbdm_ctx_destroy(self.ctx)
+            for sl in self._slots:
+                self.lib.kbdm_ctx_destroy(sl.ctx)
+            self._slots = []
             self.ctx = None
 
 

@@ -46,7 +46,7 @@ def kbdm(data, dwell, m=None, p=1, l=None, q=0, engine=None):
     if q > 0:
         logger.debug('Using Tikhonov Regularization with q=%f', q)      # reference kbdm.py:180
     eng = engine or default_engine()
-    res = eng.solve(data.reshape(1, -1), [0], [m], [l], p=p, q=q, dwell=dwell)
+    res = eng.solve(data.reshape(1, -1), [0], [m], [l], p=p, q=q, dwell=dwell, check=True)   # LinAlgError as kbdm.py:166,192
     info = KbdmInfo(m=m, p=p, l=l, q=q, singular_values=res.singular_values(0).copy())
     return res.line_list(0).copy(), info
 

@@ -188,21 +188,24 @@ def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, 
     labels = np.asarray(labels)
     order = np.argsort(labels, kind="stable")                 # noise (-1) first, then cluster 0, 1, ...
     sorted_labels = labels[order]
-    num_clusters = int(sorted_labels[-1]) + 1 if len(labels) and sorted_labels[-1] >= 0 else 0
-    distinct = num_clusters + (1 if len(labels) and sorted_labels[0] < 0 else 0)
-    if num_clusters == 0 or not (2 <= distinct <= len(labels) - 1):
+    values = np.unique(sorted_labels)
+    num_clusters = int(np.count_nonzero(values >= 0))          # len(set(labels) - {-1}), llckbdm.py:285
+    if num_clusters == 0 or not (2 <= len(values) <= len(labels) - 1):
         return ClusteringResult(num_clusters=0, labels=labels, clustered=np.array([]), non_clustered=np.array([]),
                                 summarized_line_list=[], clustered_silhouettes=np.array([]))
-    starts = np.searchsorted(sorted_labels, np.arange(num_clusters + 1))       # slice k = members of cluster k
+    # cluster k = the samples labelled k for k = 0 .. num_clusters - 1, as the reference's loop (llckbdm.py:294-295);
+    # every clusterer used here numbers its clusters contiguously, and a label value that is absent gives an EMPTY
+    # index set (searchsorted: start == end), never a wrong segment
+    starts = np.searchsorted(sorted_labels, np.arange(num_clusters + 1))
     members = [(np.sort(order[starts[k]:starts[k + 1]]),) for k in range(num_clusters)]   # np.nonzero-style tuples
     sil = (engine or default_engine()).silhouette_samples(transformed_samples, labels)
-    counts = np.diff(starts)
-    mean_sil = np.add.reduceat(sil[order], starts[:-1])[:num_clusters] / counts
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mean_sil = np.array([np.average(sil[ix]) if len(ix) else np.nan for (ix,) in members])   # llckbdm.py:299-301
     clustered = np.empty(num_clusters, dtype=object)
     for k, idx in enumerate(members):
         clustered[k] = idx
     return ClusteringResult(num_clusters=num_clusters, labels=labels, clustered=clustered,
-                            non_clustered=np.array((np.sort(order[:starts[0]]),)),
+                            non_clustered=np.array((np.sort(order[:np.searchsorted(sorted_labels, 0)]),)),
                             summarized_line_list=_summarize_clusters(samples=samples, clusters=members),
                             clustered_silhouettes=mean_sil)
 
@@ -210,18 +213,17 @@ def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, 
 def _summarize_clusters(samples, clusters, summarizer=np.average):
     """One line per cluster (reference llckbdm.py:324-353): `summarizer(rows, axis=0)` of the cluster's rows with the
     T2 column replaced by the decay RATE 1/T2 - i.e. T2 is summarised harmonically - and turned back afterwards.
-    `samples` is not modified.  The default (mean) is evaluated for all clusters at once as segmented sums."""
+    `samples` is not modified; only the rows of clustered samples are inverted (noise rows may hold T2 = 0)."""
     samples = np.asarray(samples, dtype=np.float64)
     index_sets = [np.asarray(c[0] if isinstance(c, tuple) else c).ravel() for c in clusters]
     if not index_sets:
         return np.array([])
-    rate_space = samples.copy()
-    rate_space[:, 1] = 1.0 / rate_space[:, 1]
-    if summarizer is None or summarizer is np.average or summarizer is np.mean:
-        flat = np.concatenate(index_sets)
-        sizes = np.array([len(ix) for ix in index_sets])
-        out = np.add.reduceat(rate_space[flat], np.concatenate(([0], np.cumsum(sizes)[:-1])), axis=0) / sizes[:, None]
-    else:
-        out = np.array([summarizer(rate_space[ix], axis=0) for ix in index_sets], dtype=np.float64)
+    if summarizer is None:
+        summarizer = np.average
+    out = np.empty((len(index_sets), samples.shape[1]), dtype=np.float64)
+    for k, ix in enumerate(index_sets):
+        rows = samples[ix]                                   # a copy (fancy index): only clustered rows are inverted
+        rows[:, 1] = 1.0 / rows[:, 1]
+        out[k] = summarizer(rows, axis=0) if len(ix) else np.nan      # the reference's own reduction: llckbdm.py:346-349
     out[:, 1] = 1.0 / out[:, 1]
     return out

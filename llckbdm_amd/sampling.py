@@ -18,17 +18,20 @@ def sample_kbdm(data, dwell, m_range, p, l, q=0, filter_invalid_features=True, e
     """
     data = np.asarray(data)
     ms, ls = [], []
+    kbdm_logger = logging.getLogger(__package__ + ".kbdm")
     for m in m_range:
         logger.info(f'Computing KBDM with m = {m}')                     # sampling.py:53
         mm, ll = _resolve_m_l(data.size, m, p, l)
+        if q > 0:                                                       # kbdm.py:180, once per member as there
+            kbdm_logger.debug('Using Tikhonov Regularization with q=%f', q)
         ms.append(mm)
         ls.append(ll)
     if not ms:
         return [], []
-    if q > 0:
-        logging.getLogger(__package__ + ".kbdm").debug('Using Tikhonov Regularization with q=%f', q)
     eng = engine or default_engine()
-    res = eng.solve(data.reshape(1, -1), np.zeros(len(ms), dtype=np.int32), ms, ls, p=p, q=q, dwell=dwell)
+    # check=True: a member the solver flags as not converged is retried once, then numpy.linalg.LinAlgError is raised,
+    # as scipy.linalg.svd / eig would inside the reference's kbdm() (kbdm.py:166,192)
+    res = eng.solve(data.reshape(1, -1), np.zeros(len(ms), dtype=np.int32), ms, ls, p=p, q=q, dwell=dwell, check=True)
     line_lists, infos = [], []
     for i, (m, ll) in enumerate(zip(ms, ls)):
         line_list = res.line_list(i)
@@ -50,12 +53,15 @@ def sample_kbdm_signals(signals, dwell, sig_idx, m_list, p=1, l=None, q=0, filte
     """
     signals = np.atleast_2d(np.asarray(signals))
     ms, ls = [], []
+    kbdm_logger = logging.getLogger(__package__ + ".kbdm")
     for m in m_list:
         mm, ll = _resolve_m_l(signals.shape[1], m, p, l)
+        if q > 0:
+            kbdm_logger.debug('Using Tikhonov Regularization with q=%f', q)
         ms.append(mm)
         ls.append(ll)
     eng = engine or default_engine()
-    res = eng.solve(signals, np.asarray(sig_idx, dtype=np.int32), ms, ls, p=p, q=q, dwell=dwell)
+    res = _solve_in_flight(eng, signals, np.asarray(sig_idx, dtype=np.int32), ms, ls, p, q, dwell)
     line_lists, infos, index = [], [], []
     for i, (m, ll) in enumerate(zip(ms, ls)):
         line_list = res.line_list(i)
@@ -66,6 +72,53 @@ def sample_kbdm_signals(signals, dwell, sig_idx, m_list, p=1, l=None, q=0, filte
             infos.append(KbdmInfo(m=m, l=ll, p=p, q=q, singular_values=res.singular_values(i).copy()))
             index.append(i)
     return line_lists, infos, index
+
+
+def _solve_in_flight(eng, signals, sig_idx, ms, ls, p, q, dwell, min_members=48):
+    """One batch, or - for a grid of several signals - one batch per group of signals with up to `eng.in_flight`
+    of them on the GPU at once (`Engine.submit`): the members of different signals are independent
+    (sampling.py:52-62), and a batch that does not fill the chip (a few hundred members) leaves most CUs idle during
+    its one-CU-per-member stages.  Returns a BatchResult in item order either way."""
+    from .engine import BatchResult
+    sig_idx = np.asarray(sig_idx, dtype=np.int32)
+    ms, ls = np.asarray(ms, dtype=np.int32), np.asarray(ls, dtype=np.int32)
+    used = np.unique(sig_idx)
+    nfl = getattr(eng, "in_flight", 1)
+    # groups: whole signals, enough members each to be worth a launch sequence, at most a chip-filling ~2k per batch
+    if nfl < 2 or not hasattr(eng, "submit") or len(used) < 2 or len(ms) < 2 * min_members or len(ms) > 6000:
+        return eng.solve(signals, sig_idx, ms, ls, p=p, q=q, dwell=dwell, check=True)
+    per_sig = {s: np.nonzero(sig_idx == s)[0] for s in used}
+    groups, cur = [], []
+    target = max(min_members, min(2048, -(-len(ms) // (2 * nfl))))
+    for s in used:
+        cur.append(s)
+        if sum(len(per_sig[x]) for x in cur) >= target:
+            groups.append(cur)
+            cur = []
+    if cur:
+        groups.append(cur)
+    pend = []
+    for g in groups:
+        idx = np.concatenate([per_sig[s] for s in g])
+        remap = {s: k for k, s in enumerate(g)}
+        sub_sig = np.array([remap[s] for s in sig_idx[idx]], dtype=np.int32)
+        pend.append((idx, eng.submit(signals[np.asarray(g)], sub_sig, ms[idx], ls[idx], p=p, q=q, dwell=dwell)))
+    line_off = np.concatenate([[0], np.cumsum(ls, dtype=np.int64)])
+    sv_off = np.concatenate([[0], np.cumsum(ms, dtype=np.int64)])
+    lines = np.empty((int(line_off[-1]), 4))
+    sv = np.empty(int(sv_off[-1]))
+    mu = np.empty(int(line_off[-1]), dtype=np.complex128)
+    keep = np.empty(int(line_off[-1]), dtype=np.uint8)
+    status = np.empty(len(ms), dtype=np.int32)
+    for idx, h in pend:
+        r = h.result(check=True)
+        for k, i in enumerate(idx):
+            lines[line_off[i]:line_off[i + 1]] = r.line_list(k)
+            mu[line_off[i]:line_off[i + 1]] = r.eigenvalues(k)
+            keep[line_off[i]:line_off[i + 1]] = r.keep[r.line_off[k]:r.line_off[k + 1]]
+            sv[sv_off[i]:sv_off[i + 1]] = r.singular_values(k)
+            status[i] = r.status[k]
+    return BatchResult(lines, sv, mu, keep, status, line_off, sv_off)
 
 
 def filter_samples(samples, amplitude_tol=1e-6):

@@ -19,11 +19,12 @@ def pytest_collection_modifyitems(config, items):
     gpu_items = [it for it in items if "gpu" in it.keywords]
     if not gpu_items:
         return
-    try:
-        from llckbdm_amd import _lib
-        have = _lib.load().kbdm_device_count() > 0
-    except Exception:
-        have = False
+    # A missing or ABI-mismatched library is an ERROR, not a reason to skip: only "the library loads and sees no
+    # device" skips.  KBDM_REQUIRE_GPU=1 (set it on a GPU runner) turns even that into a failure.
+    from llckbdm_amd import _lib
+    have = _lib.load().kbdm_device_count() > 0
+    if not have and os.environ.get("KBDM_REQUIRE_GPU") == "1":
+        raise pytest.UsageError("KBDM_REQUIRE_GPU=1 but libkbdm_hip.so sees no HIP device")
     if not have:
         skip = pytest.mark.skip(reason="no HIP device visible")
         for it in gpu_items:

@@ -9,7 +9,7 @@ from oracle import llc_oracle as L
 
 
 class OracleEngine:
-    def solve(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0):
+    def solve(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0, check=False):
         signals = np.atleast_2d(np.asarray(signals, dtype=np.complex128))
         m = np.asarray(m, dtype=np.int32)
         l = m.copy() if l is None else np.asarray(l, dtype=np.int32)

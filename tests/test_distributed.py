@@ -1,4 +1,5 @@
-"""CPU: the N>1 path (sharding + the one variable-length gather) on world_size=2 gloo.
+"""CPU: the N>1 path (sharding + the one variable-length gather) with world size 2, over the package's own
+standard-library launcher (llckbdm_amd.launch) and over a torch.distributed gloo group.
 The per-rank solver is injected: here it is the oracle (test infrastructure), on the GPU box
 it is the HIP engine."""
 import os
@@ -21,8 +22,8 @@ def test_shard_items_balanced_and_complete():
 
 
 class _OracleResult:
-    def __init__(self, lls, svs):
-        self.lls, self.svs = lls, svs
+    def __init__(self, lls, svs, status):
+        self.lls, self.svs, self.status = lls, svs, status
 
     def line_list(self, i):
         return self.lls[i]
@@ -42,31 +43,62 @@ def _oracle_solve(signals, sig_idx, ms, ls, p, q, dwell):
         ll, info = O.kbdm(signals[s], dwell, m=m, l=l, p=p, q=q, normalizer="gemm")
         lls.append(ll)
         svs.append(info.singular_values)
-    return _OracleResult(lls, svs)
+    # KBDM_TEST_STATUS: status word that the "solver" reports for every member with m == 33 (exercises the contract)
+    st = int(os.environ.get("KBDM_TEST_STATUS", "0"))
+    return _OracleResult(lls, svs, np.array([st if m == 33 else 0 for m in ms], dtype=np.int32))
 
 
-def _worker(rank, world, port, q):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+M_RANGE = [40, 64, 33, 100, 80]
+
+
+def _worker(rank, world, port, q, transport):
+    """One rank: the sharded samplers over `transport` ("tcp": launch.Rendezvous, standard library only; "gloo":
+    the same HostComm interface over a torch.distributed gloo group)."""
+    from oracle import kbdm_oracle as O
+    from llckbdm_amd.distributed import HostComm, sample_kbdm_sharded, sample_kbdm_signals_sharded
+    if transport == "tcp":
+        from llckbdm_amd.launch import Rendezvous
+        rdzv = Rendezvous(rank, world, port)
+    else:
+        from tests.gloo_rendezvous import GlooRendezvous
+        rdzv = GlooRendezvous(rank, world, port)
     try:
-        from oracle import kbdm_oracle as O
-        from llckbdm_amd.distributed import GlooComm, sample_kbdm_sharded
         sig = O.make_noisy(O.brain_sim_signal(512), 1e-3, 0)
-        m_range = [40, 64, 33, 100, 80]
-        comm = GlooComm(_oracle_solve)
-        lls, infos = sample_kbdm_sharded(sig, 5e-4, m_range, p=1, l=None, q=0, comm=comm)
+        comm = HostComm(_oracle_solve, rdzv)
+        lls, infos = sample_kbdm_sharded(sig, 5e-4, M_RANGE, p=1, l=None, q=0, comm=comm)
+        rl, ri = sample_kbdm_sharded(sig, 5e-4, M_RANGE, p=1, l=30, q=0, comm=comm, root=-1)
         # gather to one root only: the other rank gets nothing
-        rl, ri = sample_kbdm_sharded(sig, 5e-4, m_range, p=1, l=30, q=0, comm=comm, root=-1)
+        root_only = sample_kbdm_sharded(sig, 5e-4, M_RANGE, p=1, l=None, q=0, comm=comm, root=1)
+        assert (root_only[0] is None) == (rank != 1)
+        # a grid of signals (two voxels, their own member lists): item order and the item index survive the sharding
+        sigs = np.stack([sig, O.make_noisy(O.brain_sim_signal(512), 1e-3, 1)])
+        sidx = [0, 1, 1, 0, 1, 0]
+        mlist = [40, 64, 33, 100, 80, 51]
+        gl, gi, gx = sample_kbdm_signals_sharded(sigs, 5e-4, sidx, mlist, p=1, l=None, q=0, comm=comm)
+        # the status word travels with the blocks: a hard flag raises on every receiving rank, a weak one warns
+        import warnings
+        os.environ["KBDM_TEST_STATUS"] = "2"
+        try:
+            sample_kbdm_sharded(sig, 5e-4, M_RANGE, p=1, l=None, q=0, comm=comm)
+            raised = False
+        except np.linalg.LinAlgError as e:
+            raised = "member(s) [2]" in str(e)
+        os.environ["KBDM_TEST_STATUS"] = "4"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            sample_kbdm_sharded(sig, 5e-4, M_RANGE, p=1, l=None, q=0, comm=comm)
+        warned = any("weak" in str(x.message) for x in w)
+        os.environ["KBDM_TEST_STATUS"] = "0"
+        t = rdzv.max(float(rank))
         q.put((rank, [x.tolist() for x in lls], [i.m for i in infos], [x.tolist() for x in rl],
-               [i.singular_values.tolist() for i in ri]))
+               [i.singular_values.tolist() for i in ri], [x.tolist() for x in gl], [i.m for i in gi], gx, raised, warned, t))
     finally:
-        dist.destroy_process_group()
+        rdzv.close()
 
 
-def test_sharded_sampler_world2_gloo():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("transport", ["tcp", "gloo"])
+def test_sharded_sampler_world2(transport):
+    import multiprocessing as mp
     from oracle import kbdm_oracle as O
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -74,18 +106,20 @@ def test_sharded_sampler_world2_gloo():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
-    outs = sorted(q.get(timeout=180) for _ in procs)
+    outs = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     sig = O.make_noisy(O.brain_sim_signal(512), 1e-3, 0)
-    m_range = [40, 64, 33, 100, 80]
-    ref_l, ref_i = O.sample_kbdm(sig, 5e-4, m_range, p=1, l=None, q=0, normalizer="gemm")
-    ref_l30, ref_i30 = O.sample_kbdm(sig, 5e-4, m_range, p=1, l=30, q=0, normalizer="gemm")
-    for rank, lls, ms, l30, sv30 in outs:      # every rank holds the complete, ordered result, bit for bit
+    ref_l, ref_i = O.sample_kbdm(sig, 5e-4, M_RANGE, p=1, l=None, q=0, normalizer="gemm")
+    ref_l30, ref_i30 = O.sample_kbdm(sig, 5e-4, M_RANGE, p=1, l=30, q=0, normalizer="gemm")
+    sigs = np.stack([sig, O.make_noisy(O.brain_sim_signal(512), 1e-3, 1)])
+    grid_ref = [O.filter_samples(O.kbdm(sigs[s], 5e-4, m=m, normalizer="gemm")[0])
+                for s, m in zip([0, 1, 1, 0, 1, 0], [40, 64, 33, 100, 80, 51])]
+    for rank, lls, ms, l30, sv30, gl, gm, gx, raised, warned, tmax in outs:   # every rank: the complete, ordered result, bit for bit
         assert ms == [i.m for i in ref_i]
         assert len(lls) == len(ref_l)
         for a, b in zip(lls, ref_l):
@@ -95,6 +129,37 @@ def test_sharded_sampler_world2_gloo():
             assert np.array_equal(np.array(a).reshape(-1, 4), b)
         for a, info in zip(sv30, ref_i30):
             assert np.array_equal(np.array(a), info.singular_values)
+        assert gx == list(range(6)) and gm == [40, 64, 33, 100, 80, 51]
+        for a, b in zip(gl, grid_ref):
+            assert np.array_equal(np.array(a), b)
+        assert raised and warned and tmax == 1.0
+
+
+def test_rendezvous_primitives_world3():
+    """launch.Rendezvous alone: allgather / bcast / max / barrier over three ranks (threads: it is plain sockets)."""
+    import threading
+    from llckbdm_amd.launch import Rendezvous
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = {}
+
+    def run(r):
+        rz = Rendezvous(r, 3, port)
+        try:
+            out[r] = (rz.allgather(bytes([r]) * (r + 1)), rz.bcast(b"id-from-1" if r == 1 else b"", src=1), rz.max(r * 1.5),
+                      rz.exchange_id(b"x" * 128 if r == 0 else None))
+            rz.barrier()
+        finally:
+            rz.close()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    for r in range(3):
+        assert out[r] == ([b"\x00", b"\x01\x01", b"\x02\x02\x02"], b"id-from-1", 3.0, b"x" * 128)
 
 
 def test_packed_block_layout_roundtrip():
