@@ -54,9 +54,9 @@ def stage_flops(m, l):
         "k_hankel": 0.0,
         "k_svd_fac": (32.0 / 3.0) * m ** 3,          # Householder bidiagonalisation
         "k_gen(Q,P)": (32.0 / 3.0) * m ** 3,         # explicit Q and P
-        "k_bdsqr_gen": 0.0,                          # O(m^2) scalar recurrence
-        "k_bdsqr_apply": (84.0 - 64.0 / 3.0) * m ** 3,   # remainder of the 84 m^3 SVD budget
-        "k_bdsqr_sort": 0.0,
+        "k_dc_tree": (16.0 / 3.0) * m ** 3,          # divide and conquer: node products over all levels (4/3 * 4 m^3)
+        "k_dc_final": 8.0 * m ** 3,                  # L = Q X, R = P Y (complex x real)
+        "k_dc_sv": 0.0,
         "k_gemm<1>": 8.0 * m * m * l,
         "k_gemm<2>": 8.0 * l * l * m,
         "k_hess": (40.0 / 3.0) * l ** 3,             # Hessenberg reduction
@@ -267,8 +267,10 @@ def main():
     # creation, and the communicator's streams (idle most of the time) should be the ones that share
     comms = {}
     if multi:
-        for c in ctxs:
-            comms[c.value] = RcclComm(eng, world, rank, rdzv.exchange_id, force=True, ctx=c)
+        first = None
+        for c in ctxs:       # ONE communicator per process: the other contexts borrow it (gathers are issued in step order)
+            comms[c.value] = RcclComm(eng, world, rank, rdzv.exchange_id, force=True, ctx=c, share=first)
+            first = first or comms[c.value]
 
     stage_acc, nstage = {}, [0]
     timed = [False]
@@ -309,6 +311,7 @@ def main():
     last = eng.submit(*works[0][:3], works[0][2], p=1, q=0.0, dwell=DWELL, resident=True)
     ref = last.result(check=False)
     ok = int((ref.status == 0).sum())
+    n0 = last.plan.lane0_members()        # members (the largest) whose stage timers `stage_ms` reports
     if multi:
         buf = comms[last._slot.ctx.value].gather_plan(last.plan, sizes, root=-1)       # to every rank, for the check
         off = int(sizes[:rank].sum())
@@ -360,7 +363,6 @@ def main():
         stage_ms = {k: v / max(1, nstage[0]) for k, v in stage_acc.items()}
         # stage timers are those of lane 0 (the largest members, the critical path): price its launches
         # with the flops of exactly those members; `pipeline_tflops` below uses all members
-        n0 = last.plan.lane0_members()
         lane0 = sorted((int(m) for m in ms), reverse=True)[:n0]
         fl, fl_all = {}, {}
         for m in lane0:
@@ -373,7 +375,7 @@ def main():
         achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
         # the kernel behind the dominant stage timer (lane 0 runs the QR iteration as the team kernel)
         kname = {"k_hqr": "k_hqr2_team", "k_svd_fac": "k_bidiag_panel<0>", "k_hess": "k_hess_panel",
-                 "k_gen(Q,P)": "k_gen<8>", "k_bdsqr_apply": "k_bdsqr_stream", "k_invit": "k_invit_reg<8>"}.get(dom, dom)
+                 "k_gen(Q,P)": "k_wy_update", "k_dc_final": "k_dc_final", "k_invit": "k_invit_reg<8>"}.get(dom, dom)
         # HBM bytes per launch of that kernel: NOT measured by this run - taken from the newest committed PMC passes
         # (profiles/*_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command), if any
         traffic = traffic_src = None
@@ -434,7 +436,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    for c in comms.values():
+    for c in reversed(list(comms.values())):      # borrowers detach first, the owner destroys
         c.close()
     if rdzv is not None:
         rdzv.barrier()

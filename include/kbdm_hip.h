@@ -130,6 +130,10 @@ int kbdm_plan_lane0_members(const kbdm_plan* plan);
 int kbdm_comm_unique_id(unsigned char* id_out);
 int kbdm_comm_init(kbdm_ctx* ctx, int world, int rank, const unsigned char* id);
 int kbdm_comm_destroy(kbdm_ctx* ctx);
+/* A process that keeps several contexts on one GPU (ensembles in flight) needs ONE communicator: `ctx` borrows
+ * `owner`'s (same device).  The gathers of all these contexts must then be issued in the same order on every rank, and
+ * `owner` must outlive the borrowers' last gather; kbdm_comm_destroy on a borrower only detaches. */
+int kbdm_comm_attach(kbdm_ctx* ctx, kbdm_ctx* owner);
 int64_t kbdm_packed_bytes(int64_t lines, int64_t sv, int64_t members);
 /* Packs this plan's results on the device and gathers the blocks of all `world` ranks (bytes[r] = block size of rank
  * r, blocks concatenated in rank order) with one grouped ncclSend/ncclRecv on the plan's stream: to every rank

@@ -74,6 +74,7 @@ SYMBOLS = {
     "kbdm_comm_unique_id": (c_int, [_P]),
     "kbdm_comm_init": (c_int, [_P, c_int, c_int, _P]),
     "kbdm_comm_destroy": (c_int, [_P]),
+    "kbdm_comm_attach": (c_int, [_P, _P]),
     "kbdm_packed_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "kbdm_plan_gather": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
     "kbdm_gathered_device": (_P, [_P]),

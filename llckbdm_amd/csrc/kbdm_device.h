@@ -34,6 +34,7 @@ struct KbItem {
     long long hk_off;         // offset (complex elements) into dense per-item m*m outputs of the stage APIs
     long long rot_off;        // offset (Rot entries) of this item's rotation log
     long long hdr_off;        // offset (RotBatch entries) of this item's batch headers
+    long long dc_off;         // offset (doubles) of this item's divide-and-conquer workspace (kb_bdsdc.hpp: DcWs)
     double q;
 };
 

@@ -69,7 +69,7 @@ int env_int(const char* name, int def) {
 
 constexpr int LDS_MAX = 160 * 1024;
 
-const char* kStageNames[KBDM_NSTAGES] = {"k_hankel",  "k_svd_fac", "k_gen(Q,P)", "k_bdsqr_gen", "k_bdsqr_apply", "k_bdsqr_sort",
+const char* kStageNames[KBDM_NSTAGES] = {"k_hankel",  "k_svd_fac", "k_gen(Q,P)", "k_dc_tree", "k_dc_final", "k_dc_sv",
                                          "k_gemm<1>", "k_gemm<2>", "k_hess",     "k_gen(Qh)",   "k_hqr",         "k_invit",
                                          "k_gemm<3>", "k_gemm<4>", "k_gemm<5>",  "k_epilogue"};
 
@@ -118,11 +118,13 @@ struct kbdm_ctx {
     int win_hqr2 = KB2_WIN_DEV;   // its LDS window (fixed: the device chase is compiled for it)
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
+    int svd_dc = 1;       // bidiagonal SVD by divide and conquer (kb_bdsdc.hpp); 0: QR iteration + rotation replay (KBDM_SVD_DC)
     int nstreams = 0;     // HIP streams this context created
     int safe_replay = 0;  // 1: the rotation replay waits for the generators through a stream dependency (no in-kernel
                           // hand-off): the default when the process cannot give every stream a hardware queue of its own
     // multi-GPU: RCCL communicator (one per context) and the device buffers of the packed gather
     void* comm = nullptr;
+    bool comm_owned = false;      // false: borrowed from another context of this process (kbdm_comm_attach)
     int comm_world = 0, comm_rank = 0;
     char* d_pack = nullptr;
     char* d_gather = nullptr;
@@ -146,7 +148,8 @@ struct kbdm_plan {
     std::vector<Chunk> chunks;
     std::vector<int64_t> line_off, sv_off;
     int64_t total_lines = 0, total_sv = 0;
-    size_t arena_elems = 0, varena_elems = 0, rot_elems = 0, hdr_elems = 0;
+    size_t arena_elems = 0, varena_elems = 0, rot_elems = 0, hdr_elems = 0, dc_elems = 0;
+    double* d_dc = nullptr;        // divide-and-conquer workspace (doubles)
     Rot* d_rot = nullptr;
     RotBatch* d_hdr = nullptr;
     int* d_iwork = nullptr;
@@ -174,9 +177,11 @@ struct kbdm_plan {
 
 namespace {
 
-size_t item_arena_elems(int m, int l) {
+size_t item_arena_elems(int m, int l, int svd_dc = 1) {
     (void)l;
-    // A, Q, P, R, H : m*m complex each; rotation log (32 B per step) counted in complex units
+    // A, Q, P, R, H : m*m complex each; then, counted in complex units, the divide-and-conquer workspace (six real m x m
+    // arrays) or the rotation log of the QR-iteration route (32 B per step)
+    if (svd_dc) return 5 * (size_t)m * m + (size_t)(dc_ws_doubles(m) + 1) / 2;
     return 5 * (size_t)m * m + 2 * (size_t)bdsqr_log_steps_cap(m) + (size_t)bdsqr_log_batches_cap(m);
 }
 
@@ -186,6 +191,7 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_gen), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_sort), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_setup), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -233,25 +239,30 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
     // chunks: consecutive sorted items whose workspace fits the budget
     const size_t budget = (size_t)(ctx->ws_budget_gib * 1024.0 * 1024.0 * 1024.0) / sizeof(cd);
     pl->chunks.clear();
-    size_t used = 0, vused = 0, rused = 0, hused = 0, acct = 0;
+    size_t used = 0, vused = 0, rused = 0, hused = 0, dused = 0, acct = 0;
     Chunk cur;
     pl->arena_elems = 0;
     pl->varena_elems = 0;
     for (int pos = 0; pos < B; ++pos) {
         KbItem& it = pl->items[pl->perm[pos]];
-        const size_t need = item_arena_elems(it.m, it.l);
+        const size_t need = item_arena_elems(it.m, it.l, ctx->svd_dc);
         if (need > budget) return fail(KBDM_E_NOMEM, "one item exceeds the workspace budget");
         if (cur.count > 0 && acct + need > budget) {
             pl->chunks.push_back(cur);
             cur = Chunk();
             cur.first = pos;
-            used = 0; vused = 0; rused = 0; hused = 0; acct = 0;
+            used = 0; vused = 0; rused = 0; hused = 0; dused = 0; acct = 0;
         }
         acct += need;
-        it.rot_off = (long long)rused; rused += (size_t)bdsqr_log_steps_cap(it.m);
-        it.hdr_off = (long long)hused; hused += (size_t)bdsqr_log_batches_cap(it.m);
-        pl->rot_elems = std::max(pl->rot_elems, rused);
-        pl->hdr_elems = std::max(pl->hdr_elems, hused);
+        if (ctx->svd_dc) {
+            it.dc_off = (long long)dused; dused += (size_t)dc_ws_doubles(it.m);
+            pl->dc_elems = std::max(pl->dc_elems, dused);
+        } else {
+            it.rot_off = (long long)rused; rused += (size_t)bdsqr_log_steps_cap(it.m);
+            it.hdr_off = (long long)hused; hused += (size_t)bdsqr_log_batches_cap(it.m);
+            pl->rot_elems = std::max(pl->rot_elems, rused);
+            pl->hdr_elems = std::max(pl->hdr_elems, hused);
+        }
         const size_t M = (size_t)it.m * it.m;
         size_t o = used;
         it.off[KB_BUF_A] = o; o += M;
@@ -318,6 +329,7 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_team, sizeof(TeamCtl) * std::max(B, 1)));
     HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS *
                                        std::max(team_rec_bytes(pl->ctx->ns_hqr, std::max(pl->ctx->win_hqr, 8)), team2_rec_bytes(pl->ctx->win_hqr2))));
+    HIPCHK(hipMalloc(&pl->d_dc, sizeof(double) * std::max<size_t>(pl->dc_elems, 1)));
     HIPCHK(hipMalloc(&pl->d_rot, sizeof(Rot) * std::max<size_t>(pl->rot_elems, 1)));
     HIPCHK(hipMalloc(&pl->d_hdr, sizeof(RotBatch) * std::max<size_t>(pl->hdr_elems, 1)));
     if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
@@ -392,6 +404,68 @@ int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream
     return KBDM_OK;
 }
 
+// Bidiagonal SVD by divide and conquer (kb_bdsdc.hpp, kbdm_dc_kernels.hpp): the tree needs only (d, e) and runs on the
+// side stream while the main stream accumulates Q and P; then L = Q X and R = P Y as real GEMMs.
+int launch_svd_dc(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
+    kbdm_ctx* ctx = pl->ctx;
+    Lane& ln = ctx->lanes[ch.lane];
+    hipStream_t st = ln.stream;
+    hipStream_t ds = ln.stream2;                    // (a lane without a side stream runs the tree in stream order)
+    const int* perm = pl->d_perm + ch.first;
+    if (ds != st) {
+        HIPCHK(hipEventRecord(ln.ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ds, ln.ev_fork, 0));
+    }
+    // per step: the deepest level any member still has, and the largest node of that step
+    const int Lmax = dc_depth(ch.mmax);
+    std::vector<int> nmax(Lmax, 0), dmax(Lmax, -1);
+    {
+        int last_m = -1;
+        for (int i = 0; i < ch.count; ++i) {
+            const int m = pl->items[pl->perm[ch.first + i]].m;
+            if (m == last_m) continue;               // (sorted by m: equal sizes are adjacent)
+            last_m = m;
+            const int L = dc_depth(m);
+            for (int s = 0; s < L; ++s) {
+                const int depth = L - 1 - s;
+                int n = m;
+                for (int k = 0; k < depth; ++k) n = n - 1 - (n - 1) / 2;      // the larger child
+                nmax[s] = std::max(nmax[s], n);
+                dmax[s] = std::max(dmax[s], depth);
+            }
+        }
+    }
+    {
+        const int sm = KB_RED_BYTES + dc_leaf_scratch_bytes(KB_DC_LEAF);
+        hipLaunchKernelGGL(k_dc_leaf, dim3(1 << Lmax, ch.count), dim3(64), sm, ds, pl->d_items, perm, pl->d_varena, pl->d_dc, sm);
+    }
+    for (int s = 0; s < Lmax; ++s) {
+        const int sm = KB_RED_BYTES + dc_merge_scratch_bytes(nmax[s]);
+        if (sm > LDS_MAX - 64) return fail(KBDM_E_NOMEM, "m too large for the divide-and-conquer scratch");
+        const int nt = std::min(1024, std::max(64, (nmax[s] + 63) / 64 * 64));
+        hipLaunchKernelGGL(k_dc_setup, dim3(1 << dmax[s], ch.count), dim3(nt), sm, ds, pl->d_items, perm, pl->d_varena,
+                           pl->d_dc, s, pl->d_status, sm);
+        const int tmax = (nmax[s] + 1 + 63) / 64;
+        hipLaunchKernelGGL(k_dc_apply, dim3((1 << dmax[s]) * tmax * tmax, 2, ch.count), dim3(256), 0, ds, pl->d_items, perm,
+                           pl->d_dc, s, tmax);
+    }
+    if (ds != st) HIPCHK(hipEventRecord(ln.ev_join, ds));
+    {
+        int r = launch_gen(pl, ch, ch.mmax, 0, 2, st);
+        if (r) return r;
+        if (tm) { r = tm->mark(); if (r) return r; }
+        if (ds != st) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
+        if (tm) { r = tm->mark(); if (r) return r; }      // k_dc_tree slot (overlapped with k_gen(Q,P))
+    }
+    hipLaunchKernelGGL(k_dc_final, dim3((2 * ch.mmax + 63) / 64, (ch.mmax + 63) / 64, 2 * ch.count), dim3(256), 0, st,
+                       pl->d_items, perm, pl->d_arena, pl->d_dc);
+    if (tm) { int r = tm->mark(); if (r) return r; }
+    hipLaunchKernelGGL(k_dc_sv, dim3(ch.count), dim3(256), KB_RED_BYTES, st, pl->d_items, perm, pl->d_varena, pl->d_dc, pl->d_sv);
+    if (tm) { int r = tm->mark(); if (r) return r; }
+    HIPCHK(hipGetLastError());
+    return KBDM_OK;
+}
+
 int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     kbdm_ctx* ctx = pl->ctx;
     Lane& ln = ctx->lanes[ch.lane];
@@ -423,6 +497,7 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                            pl->d_varena, sm, npan > 0 ? 1 : 0);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
+    if (ctx->svd_dc) return launch_svd_dc(pl, ch, tm);
     // The scalar QR iteration needs only (d, e): it runs on the side stream while the main
     // stream accumulates Q and P.  (Its stage timer therefore shows ~0; k_gen(Q,P)'s slot spans
     // max(k_gen, k_bdsqr_gen).)
@@ -729,6 +804,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->hqr_v = env_int("KBDM_HQR_V", c->hqr_v);
     c->blocked = env_int("KBDM_BLOCKED", c->blocked);
     c->gen_wy = env_int("KBDM_GEN_WY", c->gen_wy);
+    c->svd_dc = env_int("KBDM_SVD_DC", c->svd_dc);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
     c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
     c->stream_wpb = env_int("KBDM_STREAM_WPB", c->stream_wpb);
@@ -788,7 +864,7 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
     hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork); hipFree(pl->d_rot); hipFree(pl->d_hdr);
-    hipFree(pl->d_team); hipFree(pl->d_rings);
+    hipFree(pl->d_team); hipFree(pl->d_rings); hipFree(pl->d_dc);
     if (pl->h_signals) hipHostFree(pl->h_signals);
     if (pl->h_out) hipHostFree(pl->h_out);
     for (auto& ch : pl->chunks)
@@ -921,7 +997,7 @@ int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l) {
     double tot = 0.0;
     for (int i = 0; i < B; ++i) {
         const int li = l ? l[i] : m[i];
-        tot += (double)item_arena_elems(m[i], li) * sizeof(cd) + 9.0 * 8.0 * (m[i] + 2) + 64.0 * li + 8.0 * m[i] +
+        tot += (double)item_arena_elems(m[i], li, env_int("KBDM_SVD_DC", 1)) * sizeof(cd) + 9.0 * 8.0 * (m[i] + 2) + 64.0 * li + 8.0 * m[i] +
                (double)KB_TEAM_SLOTS * 4096.0 + 512.0;
     }
     return (int64_t)tot;
@@ -930,7 +1006,7 @@ int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l) {
 int64_t kbdm_plan_workspace_bytes(const kbdm_plan* pl) {
     if (!pl) return 0;
     return (int64_t)(sizeof(cd) * pl->arena_elems + sizeof(double) * pl->varena_elems + sizeof(Rot) * pl->rot_elems +
-                     sizeof(RotBatch) * pl->hdr_elems + 57 * (size_t)pl->total_lines + 8 * (size_t)pl->total_sv +
+                     sizeof(double) * pl->dc_elems + sizeof(RotBatch) * pl->hdr_elems + 57 * (size_t)pl->total_lines + 8 * (size_t)pl->total_sv +
                      (size_t)pl->B * (sizeof(KbItem) + sizeof(TeamCtl) + 24) + sizeof(cd) * (size_t)pl->S * pl->N);
 }
 
@@ -1078,16 +1154,29 @@ int kbdm_comm_init(kbdm_ctx* ctx, int world, int rank, const unsigned char* id) 
     KbUid uid;
     memcpy(uid.b, id, KBDM_UNIQUE_ID_BYTES);
     NCCLCHK(g_rccl.CommInitRank(&ctx->comm, world, uid, rank));
+    ctx->comm_owned = true;
     ctx->comm_world = world;
     ctx->comm_rank = rank;
+    return KBDM_OK;
+}
+
+int kbdm_comm_attach(kbdm_ctx* ctx, kbdm_ctx* owner) {
+    if (!ctx || !owner || !owner->comm || ctx == owner) return fail(KBDM_E_INVALID, "bad attach arguments");
+    if (ctx->comm) return fail(KBDM_E_INVALID, "the context already has a communicator");
+    if (ctx->device != owner->device) return fail(KBDM_E_INVALID, "contexts on different devices cannot share a communicator");
+    ctx->comm = owner->comm;
+    ctx->comm_owned = false;
+    ctx->comm_world = owner->comm_world;
+    ctx->comm_rank = owner->comm_rank;
     return KBDM_OK;
 }
 
 int kbdm_comm_destroy(kbdm_ctx* ctx) {
     if (!ctx || !ctx->comm) return KBDM_OK;
     hipStreamSynchronize(ctx->stream);
-    g_rccl.CommDestroy(ctx->comm);
+    if (ctx->comm_owned) g_rccl.CommDestroy(ctx->comm);
     ctx->comm = nullptr;
+    ctx->comm_owned = false;
     ctx->comm_world = 0;
     return KBDM_OK;
 }

@@ -466,6 +466,8 @@ __global__ void __launch_bounds__(256) k_wy_update(const KbItem* __restrict__ it
         KB_NB / KB_TU_KC);
 }
 
+#include "kbdm_dc_kernels.hpp"
+
 // Bidiagonal QR iteration, part 1: one wavefront per item runs the scalar recurrence on
 // (d, e) in LDS and logs every plane rotation.  iwork[4*item + {0,1,3}] = batches, info, DONE.
 // The DONE word is published with an agent-scope release so that the replay kernel, which may

@@ -75,12 +75,15 @@ class RcclComm:
     (rank 0 passes the id it created, the others pass None): `launch.Rendezvous.exchange_id`.  Nothing else crosses
     Python."""
 
-    def __init__(self, engine, world, rank, exchange_id, force=False, ctx=None):
+    def __init__(self, engine, world, rank, exchange_id, force=False, ctx=None, share=None):
         self.engine, self.world, self.rank = engine, int(world), int(rank)
         self.ctx = engine.ctx if ctx is None else ctx
         lib = engine.lib
         self.owns = self.world > 1 or force         # force: a one-rank communicator (rehearsal of the RCCL path)
-        if self.owns:
+        if self.owns and share is not None:
+            # another context of this process on the same GPU: borrow `share`'s communicator (kbdm_comm_attach)
+            _lib.check(lib.kbdm_comm_attach(self.ctx, share.ctx))
+        elif self.owns:
             uid = None
             if self.rank == 0:
                 buf = np.zeros(_lib.KBDM_UNIQUE_ID_BYTES, dtype=np.uint8)

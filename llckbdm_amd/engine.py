@@ -246,7 +246,7 @@ class Engine:
 
     # the second / third batch of a burst starts when the one before it has reached this stage: pipelines with the
     # same cycle keep the phase they start in, and started together they meet panels against panels
-    STAGGER_STAGE = {2: "k_hess", 3: "k_bdsqr_sort"}
+    STAGGER_STAGE = {2: "k_hess", 3: "k_dc_sv"}
 
     def __init__(self, device=None, in_flight=None):
         self.lib = _lib.load()
@@ -506,6 +506,13 @@ class Engine:
                 self.lib.kbdm_ctx_destroy(sl.ctx)
             self._slots = []
             self.ctx = None
+
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def default_engine():

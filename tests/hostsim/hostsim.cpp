@@ -16,6 +16,7 @@
 #include "kb_hqr_ms.hpp"
 #include "kb_hqr2.hpp"
 #include "kb_svd.hpp"
+#include "kb_bdsdc.hpp"
 
 using namespace kb;
 typedef std::complex<double> zc;
@@ -54,6 +55,37 @@ static void hs_bidiag_blocked(HostCtx& ctx, int m, cd* A, double* d, double* e, 
 
 extern "C" {
 
+// Bidiagonal divide and conquer (kb_bdsdc.hpp) exactly as the device sequences it: leaves, then one depth after the
+// other (setup + the two products per node).  d, e: m and m-1 (e is read up to m-1 entries); X, Y: m x m column-major;
+// s descending.  Returns the info word (1 = a secular root hit the iteration limit).
+int hs_bdsdc(const double* d_in, const double* e_in, int m, double* X, double* s, double* Y) {
+    std::vector<double> d(d_in, d_in + m), e(m, 0.0);
+    for (int i = 0; i + 1 < m; ++i) e[i] = e_in[i];
+    std::vector<double> wsb(dc_ws_doubles(m), 0.0);
+    DcWs ws = dc_ws(wsb.data(), m);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, dc_merge_scratch_bytes(m) + dc_leaf_scratch_bytes(KB_DC_LEAF));
+    const int L = dc_depth(m);
+    int info = 0;
+    const double scale = dc_scale(ctx, d.data(), e.data(), m);
+    for (int idx = 0; idx < (1 << L); ++idx) {
+        const DcNode nd = dc_node(m, L, idx);
+        dc_leaf(ctx, d.data(), e.data(), m, nd, ws.U[L & 1], ws.V[L & 1], ws.D[L & 1], L == 0, scale);
+    }
+    for (int depth = L - 1; depth >= 0; --depth) {
+        const int src = (depth + 1) & 1;
+        for (int idx = 0; idx < (1 << depth); ++idx) {
+            const DcNode nd = dc_node(m, depth, idx);
+            dc_merge_setup(ctx, d.data(), e.data(), ws, nd, src, depth == 0, &info, scale);
+            dc_merge_apply_ref(ws, nd, src);
+        }
+    }
+    memcpy(X, ws.U[0], sizeof(double) * m * m);
+    memcpy(Y, ws.V[0], sizeof(double) * m * m);
+    for (int i = 0; i < m; ++i) s[i] = ws.D[0][i] * scale;
+    return info;
+}
+
 // A (m x m column-major) -> L (m x m), s (m), R (m x m), A = L diag(s) R^H
 int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_out) {
     std::vector<cd> A(m * m), Q(m * m), P(m * m), UR(m * m), tq(m), tp(m);
@@ -65,6 +97,24 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
     int info = 0, nb = 0;
+    const char* dcz = getenv("HS_SVD_DC");
+    if (!dcz || atoi(dcz) != 0) {
+        // divide and conquer on (d, e), then L = Q X, R = P Y (what the device does: kb_bdsdc.hpp + real GEMMs)
+        std::vector<double> X((size_t)m * m), Y((size_t)m * m);
+        info = hs_bdsdc(d.data(), e.data(), m, X.data(), s_out, Y.data());
+        cd* Lo = reinterpret_cast<cd*>(L_out);
+        cd* Ro = reinterpret_cast<cd*>(R_out);
+        for (int c = 0; c < m; ++c)
+            for (int r = 0; r < m; ++r) {
+                cd l = czero(), rr = czero();
+                for (int k = 0; k < m; ++k) {
+                    l = l + X[k + (size_t)c * m] * Q[r + (size_t)k * m];
+                    rr = rr + Y[k + (size_t)c * m] * P[r + (size_t)k * m];
+                }
+                Lo[r + (size_t)c * m] = l; Ro[r + (size_t)c * m] = rr;
+            }
+        return info;
+    }
     std::vector<RotBatch> hdr(bdsqr_log_batches_cap(m));
     std::vector<Rot> rot(bdsqr_log_steps_cap(m));
     bdsqr_gen(ctx, m, d.data(), e.data(), hdr.data(), rot.data(), &nb, &info);

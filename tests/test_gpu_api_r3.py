@@ -29,11 +29,16 @@ def _small_c2(seed, step=6):
     return sigs, sig_idx[::step], ms[::step]
 
 
-def test_flagged_members_are_retried_and_come_back_correct(eng, monkeypatch):
-    """The replay's poll budget cut to one look flags the large members (status bit 1: test_gpu_parity_r2); through the
+def test_flagged_members_are_retried_and_come_back_correct(monkeypatch):
+    """(On the QR-iteration route of the bidiagonal SVD, KBDM_SVD_DC=0: the one place with an in-kernel hand-off that
+    can be disturbed from outside.)  The replay's poll budget cut to one look flags the large members (status bit 1: test_gpu_parity_r2); through the
     drop-in `sample_kbdm` the caller never sees that: the flagged members are solved again in the conservative modes
     (stream-dependency replay, solo QR iteration) and every line equals the undisturbed run's."""
+    from llckbdm_amd.engine import Engine
     from llckbdm_amd.sampling import sample_kbdm
+    monkeypatch.setenv("KBDM_SVD_DC", "0")
+    monkeypatch.setenv("KBDM_BDSQR_FLAG", "1")
+    eng = Engine(0, in_flight=1)
     sigs, _, ms = _small_c2(3)
     good_l, good_i = sample_kbdm(sigs[0], DWELL, ms.tolist(), p=1, l=None, q=0, engine=eng)
     monkeypatch.setenv("KBDM_BDSQR_SPIN_LIMIT", "1")
@@ -46,6 +51,7 @@ def test_flagged_members_are_retried_and_come_back_correct(eng, monkeypatch):
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(ia.singular_values, ib.singular_values, rtol=0, atol=1e-13 * ib.singular_values[0])
+    eng.close()
 
 
 def test_failure_that_survives_the_retry_raises_linalgerror(eng, monkeypatch):

@@ -209,7 +209,12 @@ def test_one_pass_bidiagonalisation_panel_matches_two_pass(hs):
         assert np.abs(Q1.conj().T @ Q1 - np.eye(m)).max() < 1e-13 and np.abs(P1.conj().T @ P1 - np.eye(m)).max() < 1e-13
 
 
-def test_streaming_replay_matches_reference_replay(hs):
+def test_streaming_replay_matches_reference_replay(hs, monkeypatch):
+    monkeypatch.setenv("HS_SVD_DC", "0")          # the QR-iteration route (KBDM_SVD_DC=0 on the device)
+    _streaming_replay(hs)
+
+
+def _streaming_replay(hs):
     """bdsqr_stream_lane (the device replay's per-lane routine: register window, the sweeps of a set as a wavefront) against
     the reference replay (sweep by sweep from the definition): same factors to rounding; also when the replay resumes at set
     boundaries (`split`: what the device does while the generator is still running)."""
@@ -225,3 +230,74 @@ def test_streaming_replay_matches_reference_replay(hs):
             assert np.array_equal(s, s0)
             assert np.abs(L - L0).max() < 1e-13 and np.abs(R - R0).max() < 1e-13
             assert np.abs(L @ np.diag(s) @ R.conj().T - A).max() < 1e-12 * m
+
+
+def _bdsdc(hs, d, e):
+    m = len(d)
+    hs.hs_bdsdc.argtypes = [P, P, ctypes.c_int, P, P, P]
+    d = np.ascontiguousarray(d, float)
+    e = np.ascontiguousarray(np.r_[e, 0.0], float)
+    X, Y, s = np.zeros((m, m), order="F"), np.zeros((m, m), order="F"), np.zeros(m)
+    info = hs.hs_bdsdc(d.ctypes.data_as(P), e.ctypes.data_as(P), m, X.ctypes.data_as(P), s.ctypes.data_as(P), Y.ctypes.data_as(P))
+    return X, s, Y, info
+
+
+def _check_bdsdc(hs, d, e, tol=2e-14):
+    n = len(d)
+    B = np.diag(d) + (np.diag(e, 1) if n > 1 else 0)
+    X, s, Y, info = _bdsdc(hs, d, e)
+    sref = np.linalg.svd(B, compute_uv=False)
+    s0 = max(sref[0], 1e-300)
+    assert info == 0
+    assert np.all(np.diff(s) <= 0) and np.all(s >= 0)
+    assert np.abs(s - sref).max() <= tol * s0
+    assert np.abs(X * s @ Y.T - B).max() <= tol * s0
+    assert np.abs(X.T @ X - np.eye(n)).max() <= tol and np.abs(Y.T @ Y - np.eye(n)).max() <= 2 * tol
+
+
+def test_bidiagonal_divide_and_conquer(hs):
+    """kb_bdsdc.hpp (the templates k_dc_* instantiate) against numpy: random, graded, clustered, rank-deficient,
+    badly scaled and all-zero bidiagonals, sizes across the leaf / tree boundaries."""
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 5, 32, 33, 65, 66, 130, 257):
+        _check_bdsdc(hs, rng.standard_normal(n), rng.standard_normal(n - 1))
+    _check_bdsdc(hs, np.ones(64), np.ones(63))
+    _check_bdsdc(hs, 2.0 ** -np.arange(60), 2.0 ** -np.arange(59))
+    _check_bdsdc(hs, np.r_[np.ones(30), 1e-9 * np.ones(30)], 1e-12 * np.ones(59))
+    _check_bdsdc(hs, np.zeros(40), np.ones(39))
+    _check_bdsdc(hs, np.ones(40), np.zeros(39))
+    _check_bdsdc(hs, np.zeros(70), np.zeros(69))
+    for trial in range(40):
+        n = int(rng.integers(1, 200))
+        d, e = rng.standard_normal(n), rng.standard_normal(max(n - 1, 0))
+        kind = trial % 8
+        if kind == 1: d *= 10.0 ** rng.uniform(-12, 0, n)
+        if kind == 2: e *= 10.0 ** rng.uniform(-16, 0, max(n - 1, 0))
+        if kind == 3: d[rng.random(n) < 0.2] = 0.0
+        if kind == 4: e[rng.random(max(n - 1, 0)) < 0.2] = 0.0
+        if kind == 5: d, e = np.round(d * 2) / 2, np.round(e * 2) / 2
+        if kind == 6: d, e = d * 1e150, e * 1e150
+        if kind == 7: d, e = d * 1e-150, e * 1e-150
+        _check_bdsdc(hs, d, e)
+
+
+def test_divide_and_conquer_on_kbdm_hankel_bidiagonals(hs):
+    """The bidiagonal forms this path actually sees: Hankel matrices of the brain-sim signal, noise-free (singular values
+    down to 1e-16 s0: heavy deflation) and noisy, through hs_bidiag + hs_bdsdc."""
+    from oracle import kbdm_oracle as O
+    import scipy.linalg as sl
+    hs.hs_bidiag.argtypes = [P, ctypes.c_int, P, P, P, P]
+    for sigma, m, N in ((0.0, 150, 1024), (1e-3, 200, 2048), (1e-6, 256, 2048)):
+        sig = O.brain_sim_signal(N)
+        if sigma:
+            sig = O.make_noisy(sig, sigma, 1)
+        A = np.asfortranarray(sl.hankel(sig[:m], sig[m - 1:2 * m - 1]))
+        d, e = np.zeros(m), np.zeros(m)
+        Q, Pm = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F")
+        hs.hs_bidiag(A.ctypes.data_as(P), m, d.ctypes.data_as(P), e.ctypes.data_as(P), Q.ctypes.data_as(P), Pm.ctypes.data_as(P))
+        _check_bdsdc(hs, d, e[:m - 1])
+        X, s, Y, _ = _bdsdc(hs, d, e[:m - 1])
+        s_ref = np.linalg.svd(A, compute_uv=False)
+        assert np.abs(s - s_ref).max() <= 1e-14 * m * s_ref[0]
+        L, R = Q @ X, Pm @ Y
+        assert np.abs(L * s @ R.conj().T - A).max() <= 1e-13 * s_ref[0]
