@@ -656,33 +656,33 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
     {
-        const int per = invit_scratch_bytes_per_wave(ch.lmax);
-        int nw = std::min(ctx->nt_invit / 64, (LDS_MAX - 64 - KB_RED_BYTES) / per);
-        if (nw < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
-        const int sm = KB_RED_BYTES + nw * per;
         HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // eigenvalues of the solo members (side stream) and Qh
-        if (ctx->invit_reg && ch.lmax > 512 && ch.lmax <= KB_INVIT_BIG_MAXC * 64) {
-            // register-resident solves for members of up to 1280 rows (streaming form, no LDS); four wavefronts per
-            // workgroup = one per SIMD: a wavefront may then use accumulation registers next to its 256 VGPRs
-            const int wpb = 4;
-            int split = (ch.lmax + 2 * wpb - 1) / (2 * wpb);
-            split = std::max(1, std::min(split, 64));
-            hipLaunchKernelGGL(k_invit_big<KB_INVIT_BIG_MAXC>, dim3(ch.count, split), dim3(64 * wpb), 0, st, pl->d_items, perm, pl->d_arena,
-                               pl->d_varena, pl->d_mu, pl->d_status);
-        } else if (ctx->invit_reg && ch.lmax <= 512) {
-            // register-resident solves: no LDS; enough wavefronts that every one solves about two eigenvalues
-            const int wpb = 8;
-            int split = (ch.lmax + 2 * wpb - 1) / (2 * wpb);
-            split = std::max(1, std::min(split, 64));
-            dim3 grid(ch.count, split), block(64 * wpb);
-            const int chunks = (ch.lmax + 63) / 64;
-            // dynamic LDS: the multipliers of a solve, MAXC x 64 complex per wavefront
-            if (chunks <= 2) hipLaunchKernelGGL(k_invit_reg<2>, grid, block, wpb * 2 * 64 * sizeof(cd), st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
-            else if (chunks <= 4) hipLaunchKernelGGL(k_invit_reg<4>, grid, block, wpb * 4 * 64 * sizeof(cd), st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
-            else hipLaunchKernelGGL(k_invit_reg<8>, grid, block, wpb * 8 * 64 * sizeof(cd), st, pl->d_items, perm, pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status);
-        } else
-        hipLaunchKernelGGL(k_invit, dim3(ch.count, ctx->split_invit), dim3(ctx->nt_invit), sm, st, pl->d_items, perm,
-                           pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm);
+        // One launch per SIZE CLASS of the members of the chunk (a member is solved by the same kernel instantiation in
+        // every batch): l <= 128, <= 256, <= 512 register-resident with the multipliers in LDS; <= 1280 the streaming
+        // form (four wavefronts per workgroup = one per SIMD: a wavefront may then use accumulation registers next to
+        // its 256 VGPRs); beyond that (or with KBDM_INVIT_REG=0) the LDS-resident form.
+        int lmaxc[5] = {0, 0, 0, 0, 0};                   // largest l per class
+        int cfirst[5] = {0, 0, 0, 0, 0}, clast[5] = {-1, -1, -1, -1, -1};   // range of the chunk that holds the class
+        for (int i = 0; i < ch.count; ++i) {
+            const int l = pl->items[pl->perm[ch.first + i]].l;
+            const int c = !ctx->invit_reg ? 4 : (l <= 128 ? 0 : l <= 256 ? 1 : l <= 512 ? 2 : l <= KB_INVIT_BIG_MAXC * 64 ? 3 : 4);
+            if (!lmaxc[c]) cfirst[c] = i;
+            clast[c] = i;
+            lmaxc[c] = std::max(lmaxc[c], l);
+        }
+        auto nsplit = [](int lmax, int wpb) { return std::max(1, std::min((lmax + 2 * wpb - 1) / (2 * wpb), 64)); };
+        if (lmaxc[0]) hipLaunchKernelGGL(k_invit_reg<2>, dim3(clast[0] - cfirst[0] + 1, nsplit(lmaxc[0], 8)), dim3(512), 8 * 2 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[0], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 0);
+        if (lmaxc[1]) hipLaunchKernelGGL(k_invit_reg<4>, dim3(clast[1] - cfirst[1] + 1, nsplit(lmaxc[1], 8)), dim3(512), 8 * 4 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[1], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 128);
+        if (lmaxc[2]) hipLaunchKernelGGL(k_invit_reg<8>, dim3(clast[2] - cfirst[2] + 1, nsplit(lmaxc[2], 8)), dim3(512), 8 * 8 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[2], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 256);
+        if (lmaxc[3]) hipLaunchKernelGGL(k_invit_big<KB_INVIT_BIG_MAXC>, dim3(clast[3] - cfirst[3] + 1, nsplit(lmaxc[3], 4)), dim3(256), 0, st, pl->d_items, perm + cfirst[3], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 512);
+        if (lmaxc[4]) {
+            const int per4 = invit_scratch_bytes_per_wave(lmaxc[4]);
+            int nw4 = std::min(ctx->nt_invit / 64, (LDS_MAX - 64 - KB_RED_BYTES) / per4);
+            if (nw4 < 1) return fail(KBDM_E_NOMEM, "l too large for the inverse-iteration scratch");
+            const int sm4 = KB_RED_BYTES + nw4 * per4;
+            hipLaunchKernelGGL(k_invit, dim3(clast[4] - cfirst[4] + 1, ctx->split_invit), dim3(ctx->nt_invit), sm4, st, pl->d_items, perm + cfirst[4],
+                               pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm4, ctx->invit_reg ? KB_INVIT_BIG_MAXC * 64 : 0);
+        }
         HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));   // Qh ready before k_gemm<3>
         if (tm) { int r = tm->mark(); if (r) return r; }
     }

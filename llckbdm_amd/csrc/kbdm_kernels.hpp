@@ -906,9 +906,10 @@ __global__ void __launch_bounds__(512) k_hqr2_team(const KbItem* __restrict__ it
 
 __global__ void __launch_bounds__(1024) k_invit(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                  cd* arena, double* varena, const cd* mu_out, int* status,
-                                                 int smem_bytes) {
+                                                 int smem_bytes, int nmin) {
     const int item = perm[blockIdx.x];
     const KbItem it = items[item];
+    if (it.l <= nmin) return;
     const DevCtx ctx = make_ctx(smem_bytes);
     const int n = it.l;
     const cd* Hw = arena + it.off[KB_BUF_P];     // H above the Householder vectors of k_hess
@@ -928,11 +929,13 @@ __global__ void __launch_bounds__(1024) k_invit(const KbItem* __restrict__ items
 // the eigenvalues kk = (global wavefront index), + (wavefronts per member), ...
 template <int MAXC>
 __global__ void __launch_bounds__(512) k_invit_reg(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                    cd* arena, double* varena, const cd* mu_out, int* status) {
+                                                    cd* arena, double* varena, const cd* mu_out, int* status, int nmin) {
     const int item = perm[blockIdx.x];
     const KbItem it = items[item];
     const int n = it.l;
-    if (n > MAXC * 64) return;                       // host picks MAXC from the largest member of the launch
+    // a member is always solved by the SAME instantiation (the smallest MAXC that holds it), whatever else is in the
+    // batch: the host launches one kernel per size class, each takes the members with nmin < l <= 64 MAXC
+    if (n > MAXC * 64 || n <= nmin) return;
     const DevCtx ctx = make_ctx(0);
     const cd* Hw = arena + it.off[KB_BUF_P];
     cd* X = arena + it.off[KB_BUF_H];
@@ -951,11 +954,11 @@ __global__ void __launch_bounds__(512) k_invit_reg(const KbItem* __restrict__ it
 // The same for members of up to MAXC * 64 = 1280 rows (STREAM form: see InvitRegState); no LDS.
 template <int MAXC>
 __global__ void __launch_bounds__(256) k_invit_big(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                    cd* arena, double* varena, const cd* mu_out, int* status) {
+                                                    cd* arena, double* varena, const cd* mu_out, int* status, int nmin) {
     const int item = perm[blockIdx.x];
     const KbItem it = items[item];
     const int n = it.l;
-    if (n > MAXC * 64) return;                       // host picks MAXC from the largest member of the launch
+    if (n > MAXC * 64 || n <= nmin) return;          // (size classes: see k_invit_reg)
     const DevCtx ctx = make_ctx(0);
     const cd* Hw = arena + it.off[KB_BUF_P];
     cd* X = arena + it.off[KB_BUF_H];
