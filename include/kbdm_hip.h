@@ -84,17 +84,12 @@ int kbdm_plan_download(kbdm_plan* plan, double* lines, double* sv, double* mu, u
 int kbdm_plan_submit(kbdm_plan* plan, const double* signals_host);
 int kbdm_plan_collect(kbdm_plan* plan, double* lines, double* sv, double* mu, uint8_t* keep, int32_t* status);
 
-/* Conservative execution modes of a plan, used by the host for the ONE retry of members whose status word reports
+/* Conservative execution mode of a plan, used by the host for the ONE retry of members whose status word reports
  * non-convergence before it raises (scipy.linalg.svd / eig raise LinAlgError there: llckbdm/kbdm.py:166,192):
- *   KBDM_MODE_SAFE_REPLAY  the rotation replay of the bidiagonal SVD waits for its generator through a stream
- *                          dependency instead of following it through in-kernel flags
- *   KBDM_MODE_SOLO_QR      every member's QR iteration runs in one workgroup (no chase + helper teams) */
-#define KBDM_MODE_SAFE_REPLAY 1
+ *   KBDM_MODE_SOLO_QR      every member's QR iteration runs in one workgroup (no chase + helper teams: the one place
+ *                          where workgroups of a launch wait for each other) */
 #define KBDM_MODE_SOLO_QR 2
 int kbdm_plan_set_mode(kbdm_plan* plan, int mode);
-/* 1 if this context defaults to KBDM_MODE_SAFE_REPLAY because the streams of this process outnumber the hardware
- * queues the runtime was initialised with (GPU_MAX_HW_QUEUES) */
-int kbdm_ctx_safe_replay(const kbdm_ctx* ctx);
 /* device bytes a plan of this geometry will allocate (before chunking) / a plan holds */
 int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l);
 int64_t kbdm_plan_workspace_bytes(const kbdm_plan* plan);

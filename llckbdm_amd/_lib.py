@@ -11,31 +11,17 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libkbdm_hip.so")
 
-# A plan runs on three HIP streams (two lanes + the critical lane's side stream).  The ROCm runtime maps streams
-# onto four hardware queues by default; once torch / RCCL streams are added they would share queues, which
-# serialises the lanes.  Effective only if HIP has not been initialised in this process yet; never overrides the
-# user's own setting.
-def _hip_runtime_mapped():
-    try:
-        with open("/proc/self/maps") as f:
-            return any("libamdhip64" in line for line in f)
-    except OSError:
-        return False
-
-
-if "GPU_MAX_HW_QUEUES" not in os.environ:
-    # If the HIP runtime is already in this process (torch, cupy, ... imported first) it may have been initialised
-    # with its default of four queues, and setting the variable now changes nothing: tell the library, which then
-    # runs the rotation replay behind a stream dependency instead of the in-kernel hand-off (kbdm_ctx_safe_replay).
-    if _hip_runtime_mapped():
-        os.environ.setdefault("KBDM_HW_QUEUES", "4")
-    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+# A plan runs on three HIP streams (two lanes + the critical lane's side stream) and an Engine keeps up to three
+# contexts in flight.  The ROCm runtime maps streams onto four hardware queues by default; streams that share a queue
+# serialise (correct, but the lanes then no longer overlap).  Effective only if HIP has not been initialised in this
+# process yet; never overrides the user's own setting.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 KBDM_ABI_VERSION = 2
 KBDM_NSTAGES = 16
 KBDM_UNIQUE_ID_BYTES = 128
 STAT_SVD_NOCONV, STAT_EIG_NOCONV, STAT_INVIT_WEAK = 1, 2, 4
-MODE_SAFE_REPLAY, MODE_SOLO_QR = 1, 2
+MODE_SOLO_QR = 2
 
 # every symbol include/kbdm_hip.h declares: (restype, argtypes)
 _P = c_void_p
@@ -58,7 +44,6 @@ SYMBOLS = {
     "kbdm_plan_submit": (c_int, [_P, _P]),
     "kbdm_plan_collect": (c_int, [_P, _P, _P, _P, _P, _P]),
     "kbdm_plan_set_mode": (c_int, [_P, c_int]),
-    "kbdm_ctx_safe_replay": (c_int, [_P]),
     "kbdm_workspace_estimate": (c_int64, [c_int, _P, _P]),
     "kbdm_plan_workspace_bytes": (c_int64, [_P]),
     "kbdm_plan_lines_device": (_P, [_P]),

@@ -14,7 +14,7 @@ enum { KB_BUF_A = 0, KB_BUF_Q, KB_BUF_P, KB_BUF_R, KB_BUF_H, KB_NBUF };
 
 // Per-item vector arena (doubles), slot s starts at voff + s * vstride.
 enum {
-    KB_V_D = 0,      // bidiagonal diagonal -> unsorted singular values
+    KB_V_D = 0,      // bidiagonal diagonal
     KB_V_E = 1,      // bidiagonal superdiagonal
     KB_V_S = 2,      // sorted singular values
     KB_V_DSQI = 3,   // 1/sqrt(s) (or Tikhonov form)
@@ -32,8 +32,6 @@ struct KbItem {
     long long line_off;       // offset of this item's lines / mu / keep (units: lines)
     long long sv_off;         // offset of this item's singular values
     long long hk_off;         // offset (complex elements) into dense per-item m*m outputs of the stage APIs
-    long long rot_off;        // offset (Rot entries) of this item's rotation log
-    long long hdr_off;        // offset (RotBatch entries) of this item's batch headers
     long long dc_off;         // offset (doubles) of this item's divide-and-conquer workspace (kb_bdsdc.hpp: DcWs)
     double q;
 };

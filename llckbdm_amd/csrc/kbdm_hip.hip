@@ -6,7 +6,6 @@
 #include <dlfcn.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,7 +25,6 @@ using namespace kb;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_streams{0};      // HIP streams created by this library in this process (all contexts)
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -95,11 +93,7 @@ struct kbdm_ctx {
     int nlanes = 2;
     double lane0_frac = 0.5;   // share of the batch's cost (sum of m^3) that lane 0 takes when there are two lanes
     int nt_fac = 1024;    // threads per workgroup: bidiagonalisation / Hessenberg kernels
-    int nt_bdsqr = 1024;
-    int nt_hqr = 512;
     int nt_invit = 1024;
-    int ns_hqr = 8;       // simultaneous shifts (bulges) of the QR iteration
-    int win_hqr = 56;     // LDS window of the bulge chase (0 = unblocked chase in global memory)
     int split_gen = 32;   // workgroups per item and matrix in k_gen (columns of one matrix are independent)
     int split_invit = 8;  // workgroups per item in k_invit
     int invit_reg = 1;    // inverse iteration with register-resident vectors for l <= 512 (0: the LDS form)
@@ -113,15 +107,10 @@ struct kbdm_ctx {
     int stream_wpb = 1;   // KBDM_STREAM_WPB: row blocks (wavefronts) per workgroup of the rotation replay
     int bidiag_fused = 0; // KBDM_BIDIAG_FUSED=1: one pass over the trailing matrix per panel column (members up to 512 rows)
     int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
-    int hqr_v = 2;        // QR iteration: 2 = kb_hqr2.hpp (double-shift bulges, systolic strips), 1 = round-1 kernels
     int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
     int win_hqr2 = KB2_WIN_DEV;   // its LDS window (fixed: the device chase is compiled for it)
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
-    int svd_dc = 1;       // bidiagonal SVD by divide and conquer (kb_bdsdc.hpp); 0: QR iteration + rotation replay (KBDM_SVD_DC)
-    int nstreams = 0;     // HIP streams this context created
-    int safe_replay = 0;  // 1: the rotation replay waits for the generators through a stream dependency (no in-kernel
-                          // hand-off): the default when the process cannot give every stream a hardware queue of its own
     // multi-GPU: RCCL communicator (one per context) and the device buffers of the packed gather
     void* comm = nullptr;
     bool comm_owned = false;      // false: borrowed from another context of this process (kbdm_comm_attach)
@@ -148,10 +137,8 @@ struct kbdm_plan {
     std::vector<Chunk> chunks;
     std::vector<int64_t> line_off, sv_off;
     int64_t total_lines = 0, total_sv = 0;
-    size_t arena_elems = 0, varena_elems = 0, rot_elems = 0, hdr_elems = 0, dc_elems = 0;
+    size_t arena_elems = 0, varena_elems = 0, dc_elems = 0;
     double* d_dc = nullptr;        // divide-and-conquer workspace (doubles)
-    Rot* d_rot = nullptr;
-    RotBatch* d_hdr = nullptr;
     int* d_iwork = nullptr;
     cd* d_signals = nullptr;
     KbItem* d_items = nullptr;
@@ -177,25 +164,20 @@ struct kbdm_plan {
 
 namespace {
 
-size_t item_arena_elems(int m, int l, int svd_dc = 1) {
+size_t item_arena_elems(int m, int l) {
     (void)l;
-    // A, Q, P, R, H : m*m complex each; then, counted in complex units, the divide-and-conquer workspace (six real m x m
-    // arrays) or the rotation log of the QR-iteration route (32 B per step)
-    if (svd_dc) return 5 * (size_t)m * m + (size_t)(dc_ws_doubles(m) + 1) / 2;
-    return 5 * (size_t)m * m + 2 * (size_t)bdsqr_log_steps_cap(m) + (size_t)bdsqr_log_batches_cap(m);
+    // A, Q, P, R, H : m*m complex each; then, counted in complex units, the divide-and-conquer workspace (six real
+    // m x m arrays)
+    return 5 * (size_t)m * m + (size_t)(dc_ws_doubles(m) + 1) / 2;
 }
 
 int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svd_fac), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_gen), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bdsqr_sort), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_setup), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -239,30 +221,23 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
     // chunks: consecutive sorted items whose workspace fits the budget
     const size_t budget = (size_t)(ctx->ws_budget_gib * 1024.0 * 1024.0 * 1024.0) / sizeof(cd);
     pl->chunks.clear();
-    size_t used = 0, vused = 0, rused = 0, hused = 0, dused = 0, acct = 0;
+    size_t used = 0, vused = 0, dused = 0, acct = 0;
     Chunk cur;
     pl->arena_elems = 0;
     pl->varena_elems = 0;
     for (int pos = 0; pos < B; ++pos) {
         KbItem& it = pl->items[pl->perm[pos]];
-        const size_t need = item_arena_elems(it.m, it.l, ctx->svd_dc);
+        const size_t need = item_arena_elems(it.m, it.l);
         if (need > budget) return fail(KBDM_E_NOMEM, "one item exceeds the workspace budget");
         if (cur.count > 0 && acct + need > budget) {
             pl->chunks.push_back(cur);
             cur = Chunk();
             cur.first = pos;
-            used = 0; vused = 0; rused = 0; hused = 0; dused = 0; acct = 0;
+            used = 0; vused = 0; dused = 0; acct = 0;
         }
         acct += need;
-        if (ctx->svd_dc) {
-            it.dc_off = (long long)dused; dused += (size_t)dc_ws_doubles(it.m);
-            pl->dc_elems = std::max(pl->dc_elems, dused);
-        } else {
-            it.rot_off = (long long)rused; rused += (size_t)bdsqr_log_steps_cap(it.m);
-            it.hdr_off = (long long)hused; hused += (size_t)bdsqr_log_batches_cap(it.m);
-            pl->rot_elems = std::max(pl->rot_elems, rused);
-            pl->hdr_elems = std::max(pl->hdr_elems, hused);
-        }
+        it.dc_off = (long long)dused; dused += (size_t)dc_ws_doubles(it.m);
+        pl->dc_elems = std::max(pl->dc_elems, dused);
         const size_t M = (size_t)it.m * it.m;
         size_t o = used;
         it.off[KB_BUF_A] = o; o += M;
@@ -328,10 +303,8 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMemset(pl->d_iwork, 0, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
     HIPCHK(hipMalloc(&pl->d_team, sizeof(TeamCtl) * std::max(B, 1)));
     HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS *
-                                       std::max(team_rec_bytes(pl->ctx->ns_hqr, std::max(pl->ctx->win_hqr, 8)), team2_rec_bytes(pl->ctx->win_hqr2))));
+                                       team2_rec_bytes(pl->ctx->win_hqr2)));
     HIPCHK(hipMalloc(&pl->d_dc, sizeof(double) * std::max<size_t>(pl->dc_elems, 1)));
-    HIPCHK(hipMalloc(&pl->d_rot, sizeof(Rot) * std::max<size_t>(pl->rot_elems, 1)));
-    HIPCHK(hipMalloc(&pl->d_hdr, sizeof(RotBatch) * std::max<size_t>(pl->hdr_elems, 1)));
     if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
     return KBDM_OK;
 }
@@ -497,51 +470,7 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                            pl->d_varena, sm, npan > 0 ? 1 : 0);
         if (tm) { int r = tm->mark(); if (r) return r; }
     }
-    if (ctx->svd_dc) return launch_svd_dc(pl, ch, tm);
-    // The scalar QR iteration needs only (d, e): it runs on the side stream while the main
-    // stream accumulates Q and P.  (Its stage timer therefore shows ~0; k_gen(Q,P)'s slot spans
-    // max(k_gen, k_bdsqr_gen).)
-    HIPCHK(hipEventRecord(ln.ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(ln.stream2, ln.ev_fork, 0));
-    {
-        const int sm = KB_RED_BYTES + bdsqr_gen_scratch_bytes(ch.mmax);
-        if (sm > LDS_MAX - 64) return fail(KBDM_E_NOMEM, "m too large for the bidiagonal QR scratch");
-        hipLaunchKernelGGL(k_bdsqr_gen, dim3(ch.count), dim3(64), sm, ln.stream2, pl->d_items, perm, pl->d_varena,
-                           pl->d_hdr, pl->d_rot, pl->d_iwork, sm);
-        HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));
-    }
-    // In-kernel hand-off (DONE flag per item) lets the replay of small members start while the
-    // generators of large members are still running.  Only when every generator wavefront is
-    // certainly resident before the replay starts (they were launched a whole kernel earlier and
-    // need one wavefront each); otherwise a stream dependency.
-    const bool flag_mode = ch.count <= 2048 && !(pl->mode & KBDM_MODE_SAFE_REPLAY) &&
-                           env_int("KBDM_BDSQR_FLAG", ctx->safe_replay ? 0 : 1) != 0;
-    {
-        int r = launch_gen(pl, ch, ch.mmax, 0, 2, st);
-        if (r) return r;
-        if (!flag_mode) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
-        if (tm) { r = tm->mark(); if (r) return r; }
-        if (tm) { r = tm->mark(); if (r) return r; }      // k_bdsqr_gen slot (overlapped)
-    }
-    {
-        // Rotation replay (streaming, no LDS): one launch for the whole chunk; with the in-kernel hand-off
-        // its wavefronts follow the generators set by set.
-        const int wpb = std::min(16, std::max(1, ctx->stream_wpb));             // wavefronts (row blocks) per workgroup
-        const int nrb = (2 * ch.mmax + 63) / 64;
-        hipLaunchKernelGGL(k_bdsqr_stream, dim3((nrb + wpb - 1) / wpb, ch.count, 2), dim3(64 * wpb), 0, st, pl->d_items,
-                           perm, pl->d_arena, pl->d_hdr, pl->d_rot, pl->d_iwork, flag_mode ? 1 : 0, pl->d_status,
-                           (unsigned)std::max(1, env_int("KBDM_BDSQR_SPIN_LIMIT", 1 << 26)));
-        if (flag_mode) HIPCHK(hipStreamWaitEvent(st, ln.ev_join, 0));
-        if (tm) { int r = tm->mark(); if (r) return r; }
-    }
-    {
-        const int sm = KB_RED_BYTES + 4 * ch.mmax + 64;
-        hipLaunchKernelGGL(k_bdsqr_sort, dim3(ch.count), dim3(ctx->nt_bdsqr), sm, st, pl->d_items, perm, pl->d_arena,
-                           pl->d_varena, pl->d_sv, pl->d_status, pl->d_iwork, sm);
-        if (tm) { int r = tm->mark(); if (r) return r; }
-    }
-    HIPCHK(hipGetLastError());
-    return KBDM_OK;
+    return launch_svd_dc(pl, ch, tm);
 }
 
 int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
@@ -581,14 +510,8 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         if (tm) { r = tm->mark(); if (r) return r; }      // k_gen(Qh) slot (overlapped with k_hqr)
     }
     {
-        const bool v2 = ctx->hqr_v >= 2;
-        int win = v2 ? ctx->win_hqr2 : ctx->win_hqr;
-        int sm = v2 ? KB_RED_BYTES + hqr2_scratch_bytes(win)
-                    : KB_RED_BYTES + (win > 0 ? hqr_win_scratch_bytes(ctx->ns_hqr, win, 64) : hqr_ms_scratch_bytes(ctx->ns_hqr));
-        if (!v2 && sm > LDS_MAX - 64) {   // window does not fit LDS with this many shifts: unblocked chase
-            win = 0;
-            sm = KB_RED_BYTES + hqr_ms_scratch_bytes(ctx->ns_hqr);
-        }
+        const int win = ctx->win_hqr2;
+        const int sm = KB_RED_BYTES + hqr2_scratch_bytes(win);
         MsStats* prof = nullptr;
         const bool do_prof = ctx->hqr_prof != 0;
         if (do_prof) {
@@ -606,12 +529,8 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             while (nteam < ch.count && nteam < cap && pl->items[pl->perm[ch.first + nteam]].l >= ctx->team_min_l) ++nteam;
         }
         if (nteam > 0) {
-            if (v2)
-                hipLaunchKernelGGL(k_hqr2_team, dim3(2 * nteam), dim3(512), sm, st, pl->d_items, perm, pl->d_arena,
-                                   pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, pl->d_team, pl->d_rings, prof);
-            else
-            hipLaunchKernelGGL(k_hqr_team, dim3(2 * nteam), dim3(ctx->nt_hqr), sm, st, pl->d_items, perm, pl->d_arena,
-                               pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, pl->d_team, pl->d_rings, prof);
+            hipLaunchKernelGGL(k_hqr2_team, dim3(2 * nteam), dim3(512), sm, st, pl->d_items, perm, pl->d_arena,
+                               pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, pl->d_team, pl->d_rings, prof);
         }
         if (ch.count > nteam) {
             hipStream_t ss = nteam > 0 ? ln.stream2 : st;
@@ -634,12 +553,8 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                 if (nwg > 192) nwg = 0;
             }
             int* queue = (nwg > 0 && nsolo > nwg && cidx < KB_QUEUE_WORDS) ? pl->d_iwork + 4 * pl->B + cidx : nullptr;
-            if (v2)
-                hipLaunchKernelGGL(k_hqr2, dim3(queue ? nwg : nsolo), dim3(512), sm, ss, pl->d_items, perm + nteam,
-                                   pl->d_arena, pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, prof, nsolo, queue);
-            else
-            hipLaunchKernelGGL(k_hqr, dim3(queue ? nwg : nsolo), dim3(ctx->nt_hqr), sm, ss, pl->d_items, perm + nteam,
-                               pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, sm, ctx->ns_hqr, win, prof, nsolo, queue);
+            hipLaunchKernelGGL(k_hqr2, dim3(queue ? nwg : nsolo), dim3(512), sm, ss, pl->d_items, perm + nteam,
+                               pl->d_arena, pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, prof, nsolo, queue);
             if (nteam > 0) HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));   // the join now covers Qh and the solo members
         }
         if (do_prof) {   // diagnostic build path only: synchronous dump of the largest item's counters
@@ -763,15 +678,12 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     kbdm_ctx* c = new kbdm_ctx();
     c->device = device;
     c->nlanes = std::min(KB_MAX_LANES, std::max(1, env_int("KBDM_LANES", c->nlanes)));
-    // hardware queues the runtime was initialised with: the host may know better than the environment (KBDM_HW_QUEUES:
-    // HIP was initialised before GPU_MAX_HW_QUEUES was set)
-    const int hwq = std::max(1, env_int("KBDM_HW_QUEUES", env_int("GPU_MAX_HW_QUEUES", 4)));
+    const int hwq = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
     const bool side_all = env_int("KBDM_SIDE_ALL", 0) != 0;
     if (const char* v = getenv("KBDM_LANE0_FRAC")) c->lane0_frac = std::min(0.95, std::max(0.05, atof(v)));
     for (int i = 0; i < c->nlanes; ++i) {
         Lane& ln = c->lanes[i];
         HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-        c->nstreams++;
         // Side streams only while every stream still has a hardware queue of its own (GPU_MAX_HW_QUEUES,
         // 4 by default): streams beyond that share queues, and two lanes whose replay kernels wait
         // (in-kernel flags) on generator kernels queued behind each other would never finish.  A lane
@@ -780,38 +692,22 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
         // they speed those lanes up - C2 182 ms instead of 175 - so they are opt-in: KBDM_SIDE_ALL=1.)
         if (i == 0 || (side_all && c->nlanes + i + 1 <= hwq)) {
             HIPCHK(hipStreamCreateWithFlags(&ln.stream2, hipStreamNonBlocking));
-            c->nstreams++;
-        } else ln.stream2 = ln.stream;
+            } else ln.stream2 = ln.stream;
         HIPCHK(hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
     }
     c->stream = c->lanes[0].stream;
-    // The in-kernel hand-off between the bidiagonal QR generator (side stream) and the rotation replay (main stream)
-    // needs both kernels resident at once, i.e. a hardware queue per stream.  The runtime reads GPU_MAX_HW_QUEUES
-    // when HIP is initialised (4 without it); streams beyond that share queues.  If this process's streams - those
-    // of every context of this library - no longer fit, this context's replay waits on a stream dependency instead
-    // (slower by the overlap, never wrong).  A host that initialised HIP before setting the variable gets the same
-    // conservative mode through KBDM_BDSQR_FLAG=0 or kbdm_plan_set_mode.
-    if (g_streams.fetch_add(c->nstreams) + c->nstreams > hwq) c->safe_replay = 1;
     HIPCHK(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
     c->nt_fac = env_int("KBDM_NT_FAC", c->nt_fac);
-    c->nt_bdsqr = env_int("KBDM_NT_BDSQR", c->nt_bdsqr);
-    c->nt_hqr = env_int("KBDM_NT_HQR", c->nt_hqr);
     c->nt_invit = env_int("KBDM_NT_INVIT", c->nt_invit);
-    c->ns_hqr = env_int("KBDM_NS_HQR", c->ns_hqr);
-    c->win_hqr = env_int("KBDM_WIN_HQR", c->win_hqr);
-    c->hqr_v = env_int("KBDM_HQR_V", c->hqr_v);
     c->blocked = env_int("KBDM_BLOCKED", c->blocked);
     c->gen_wy = env_int("KBDM_GEN_WY", c->gen_wy);
-    c->svd_dc = env_int("KBDM_SVD_DC", c->svd_dc);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
     c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
     c->stream_wpb = env_int("KBDM_STREAM_WPB", c->stream_wpb);
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
     c->win_hqr2 = KB2_WIN_DEV;                       // the device chase is compiled for this window
-    if (c->ns_hqr > KB_MS_NSMAX) c->ns_hqr = KB_MS_NSMAX;
-    if (c->win_hqr > 0 && c->win_hqr < 3 * c->ns_hqr + 8) c->win_hqr = 3 * c->ns_hqr + 8;
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
     c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
@@ -819,7 +715,6 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
     c->hqr_wgs = std::max(-1, env_int("KBDM_HQR_WGS", c->hqr_wgs));
     c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
-    if (c->nt_hqr > 512) c->nt_hqr = 512;
     if (const char* v = getenv("KBDM_WS_GIB")) c->ws_budget_gib = atof(v);
     int r = set_lds_attr();
     if (r) { delete c; return r; }
@@ -829,7 +724,6 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
 
 int kbdm_ctx_destroy(kbdm_ctx* ctx) {
     if (!ctx) return KBDM_OK;
-    g_streams.fetch_sub(ctx->nstreams);
     for (int i = 0; i < KB_MAX_LANES; ++i) {
         Lane& ln = ctx->lanes[i];
         if (ln.stream2 && ln.stream2 != ln.stream) hipStreamDestroy(ln.stream2);
@@ -863,7 +757,7 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     if (!pl) return KBDM_OK;
     hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
-    hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork); hipFree(pl->d_rot); hipFree(pl->d_hdr);
+    hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork);
     hipFree(pl->d_team); hipFree(pl->d_rings); hipFree(pl->d_dc);
     if (pl->h_signals) hipHostFree(pl->h_signals);
     if (pl->h_out) hipHostFree(pl->h_out);
@@ -984,12 +878,10 @@ int kbdm_plan_download(kbdm_plan* pl, double* lines, double* sv, double* mu, uin
 }
 
 int kbdm_plan_set_mode(kbdm_plan* pl, int mode) {
-    if (!pl || (mode & ~(KBDM_MODE_SAFE_REPLAY | KBDM_MODE_SOLO_QR))) return fail(KBDM_E_INVALID, "bad mode");
+    if (!pl || (mode & ~KBDM_MODE_SOLO_QR)) return fail(KBDM_E_INVALID, "bad mode");
     pl->mode = mode;
     return KBDM_OK;
 }
-
-int kbdm_ctx_safe_replay(const kbdm_ctx* ctx) { return ctx ? ctx->safe_replay : 0; }
 
 int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l) {
     if (B < 0 || (B > 0 && !m)) return -1;
@@ -997,7 +889,7 @@ int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l) {
     double tot = 0.0;
     for (int i = 0; i < B; ++i) {
         const int li = l ? l[i] : m[i];
-        tot += (double)item_arena_elems(m[i], li, env_int("KBDM_SVD_DC", 1)) * sizeof(cd) + 9.0 * 8.0 * (m[i] + 2) + 64.0 * li + 8.0 * m[i] +
+        tot += (double)item_arena_elems(m[i], li) * sizeof(cd) + 9.0 * 8.0 * (m[i] + 2) + 64.0 * li + 8.0 * m[i] +
                (double)KB_TEAM_SLOTS * 4096.0 + 512.0;
     }
     return (int64_t)tot;
@@ -1005,8 +897,7 @@ int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l) {
 
 int64_t kbdm_plan_workspace_bytes(const kbdm_plan* pl) {
     if (!pl) return 0;
-    return (int64_t)(sizeof(cd) * pl->arena_elems + sizeof(double) * pl->varena_elems + sizeof(Rot) * pl->rot_elems +
-                     sizeof(double) * pl->dc_elems + sizeof(RotBatch) * pl->hdr_elems + 57 * (size_t)pl->total_lines + 8 * (size_t)pl->total_sv +
+    return (int64_t)(sizeof(cd) * pl->arena_elems + sizeof(double) * pl->varena_elems + sizeof(double) * pl->dc_elems + 57 * (size_t)pl->total_lines + 8 * (size_t)pl->total_sv +
                      (size_t)pl->B * (sizeof(KbItem) + sizeof(TeamCtl) + 24) + sizeof(cd) * (size_t)pl->S * pl->N);
 }
 
@@ -1070,7 +961,11 @@ int kbdm_plan_collect(kbdm_plan* pl, double* lines, double* sv, double* mu, uint
     if (keep) memcpy(keep, h + o.keep, (size_t)pl->total_lines);
     if (status) {
         memcpy(status, h + o.status, 4 * (size_t)pl->B);
-        const int force = env_int("KBDM_DEBUG_FORCE_STATUS", 0);      // test hook: pretend the members failed
+        int force = env_int("KBDM_DEBUG_FORCE_STATUS", 0);            // test hooks: pretend the members failed
+        if (const int once = env_int("KBDM_DEBUG_FORCE_STATUS_ONCE", 0)) {     // ... in the next collected run only
+            force |= once;
+            unsetenv("KBDM_DEBUG_FORCE_STATUS_ONCE");
+        }
         if (force) for (int i = 0; i < pl->B; ++i) status[i] |= force;
     }
     return KBDM_OK;

@@ -7,8 +7,8 @@
 //   k_bidiag_panel / k_trail_update / k_svd_fac   blocked Householder bidiagonalisation: panels of
 //              32 reflector pairs, FP64-MFMA rank-64 trailing update, unblocked tail   (kbdm.py:166)
 //   k_gen      explicit Q, P (and later Qh), columns in registers  (kbdm.py:166,192)
-//   k_bdsqr_gen / _apply / _sort   bidiagonal QR: logged rotations, LDS-resident row replay,
-//              sort -> L, s, R                                      (kbdm.py:166)
+//   k_dc_*     bidiagonal SVD by divide and conquer (kbdm_dc_kernels.hpp), L = Q X, R = P Y,
+//              singular values, Dsqi                                (kbdm.py:166-186)
 //   k_gemm<1>  T1 = U^p R_        (U^p read straight from the signal: Hankel operand)
 //   k_gemm<2>  W  = Dsqi L_^H T1 Dsqi                               (kbdm.py:168-189)
 //   k_hess     Hessenberg reduction + Qh + copies                   (kbdm.py:192)
@@ -468,113 +468,6 @@ __global__ void __launch_bounds__(256) k_wy_update(const KbItem* __restrict__ it
 
 #include "kbdm_dc_kernels.hpp"
 
-// Bidiagonal QR iteration, part 1: one wavefront per item runs the scalar recurrence on
-// (d, e) in LDS and logs every plane rotation.  iwork[4*item + {0,1,3}] = batches, info, DONE.
-// The DONE word is published with an agent-scope release so that the replay kernel, which may
-// already be running on the main stream, can start on this item the moment its log is complete.
-__global__ void __launch_bounds__(64) k_bdsqr_gen(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                   double* varena, RotBatch* hdr_all, Rot* rot_all, int* iwork,
-                                                   int smem_bytes) {
-    const int item = perm[blockIdx.x];
-    const KbItem it = items[item];
-    const DevCtx ctx = make_ctx(smem_bytes);
-    double* dv = varena + it.voff;
-    bdsqr_gen(ctx, it.m, dv + KB_V_D * it.vstride, dv + KB_V_E * it.vstride, hdr_all + it.hdr_off,
-              rot_all + it.rot_off, &iwork[4 * item], &iwork[4 * item + 1], &iwork[4 * item + 2]);
-    // publish: every lane's stores drained, then release, then the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&iwork[4 * item + 3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Part 2: the logged rotations are applied to the rows of Q (blockIdx.z = 0) and P (= 1): one lane per
-// real component of a row, rows pass through a register
-// window (bdsqr_stream_lane), no LDS, so many wavefronts share a SIMD.  grid (ceil(2 m / 64), members, 2).
-__global__ void __launch_bounds__(1024) k_bdsqr_stream(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                        cd* arena, const RotBatch* hdr_all, const Rot* rot_all,
-                                                        int* iwork, int wait_flag, int* status, unsigned spin_limit) {
-    // blockDim.x / 64 independent wavefronts per workgroup (no barrier, no LDS): row block = one wavefront.  Many
-    // wavefronts per workgroup keep the long-lived replay on few CUs instead of a wavefront or two on every CU, where
-    // they would stand in the way of the workgroups that need a whole CU's registers (panels, QR iteration).
-    const int item = perm[blockIdx.y];
-    const KbItem it = items[item];
-    const int m = it.m;
-    const int rb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // row block of this wavefront
-    if (rb * 64 >= 2 * m) return;
-    const int vl = rb * 64 + (threadIdx.x & 63);
-    const bool live = vl < 2 * m;
-    double* X = reinterpret_cast<double*>(arena + it.off[blockIdx.z == 0 ? KB_BUF_Q : KB_BUF_P]);
-    const RotBatch* hdr0 = hdr_all + it.hdr_off;
-    const Rot* rot0 = rot_all + it.rot_off;
-    if (!wait_flag) {           // stream dependency on the generator: the whole log is there
-        const int nb = iwork[4 * item];
-        bdsqr_stream_lane(X + vl, live, (size_t)m, (int)blockIdx.z, hdr0, rot0, 0, nb);
-        return;
-    }
-    // Follow the generator: replay whatever sets of sweeps it has published, sleep when caught up,
-    // finish with the rest once it is done.  (One wavefront per workgroup: every lane polls
-    // the same words; the values are made uniform.)  After every successful poll: agent acquire for the
-    // vector L1, s_dcache_inv for the scalar cache the log is read through, and the log pointers are
-    // laundered so that no load of the log is reused or hoisted across the wait.
-    int b = 0;
-    unsigned spins = 0;
-    for (;;) {
-        const int done = __builtin_amdgcn_readfirstlane(
-            __hip_atomic_load(&iwork[4 * item + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        int avail = __builtin_amdgcn_readfirstlane(
-            __hip_atomic_load(&iwork[4 * item + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (!done && avail <= b) {
-            if (++spins > spin_limit) {
-                // generator lost (it never became resident: streams sharing a hardware queue, or it died): this member's
-                // Q / P stay un-replayed - flag the member, never return a silent answer
-                if ((threadIdx.x & 63) == 0) atomicOr(&status[item], KB_STAT_SVD_NOCONV);
-                return;
-            }
-            __builtin_amdgcn_s_sleep(32);
-            continue;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-        const RotBatch* hdr = hdr0;
-        const Rot* rot = rot0;
-        asm volatile("" : "+s"(hdr), "+s"(rot)::"memory");
-        if (done) avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&iwork[4 * item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        bdsqr_stream_lane(X + vl, live, (size_t)m, (int)blockIdx.z, hdr, rot, b, avail);
-        b = avail;
-        if (done) break;
-    }
-}
-
-// Part 3: sign fix, descending sort, permuted copy into L (A buffer) and R, Dsqi, outputs.
-__global__ void __launch_bounds__(1024) k_bdsqr_sort(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                      cd* arena, double* varena, double* sv_out, int* status,
-                                                      const int* iwork, int smem_bytes) {
-    const int item = perm[blockIdx.x];
-    const KbItem it = items[item];
-    const DevCtx ctx = make_ctx(smem_bytes);
-    const int m = it.m;
-    cd* Q = arena + it.off[KB_BUF_Q];
-    cd* P = arena + it.off[KB_BUF_P];
-    cd* L = arena + it.off[KB_BUF_A];
-    cd* R = arena + it.off[KB_BUF_R];
-    double* dv = varena + it.voff;
-    double* d = dv + KB_V_D * it.vstride;
-    double* s = dv + KB_V_S * it.vstride;
-    double* dsqi = dv + KB_V_DSQI * it.vstride;
-    sort_sv(ctx, m, d, Q, m, P, m, s, L, m, R, m);
-    // singular values out + the scaling Dsqi = 1/sqrt(s) (q = 0) or 1/sqrt(s + q^2/s)  [kbdm.py:179-186]
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const double si = s[i];
-        if (sv_out) sv_out[it.sv_off + i] = si;
-        if (i < it.l) dsqi[i] = (it.q > 0.0) ? 1.0 / sqrt(si + it.q * it.q / si) : 1.0 / sqrt(si);
-    }
-    if (threadIdx.x == 0 && iwork[4 * item + 1] != 0) status[item] |= KB_STAT_SVD_NOCONV;
-}
-
 // ------------------------------------------------------------------------------------
 // Batched complex GEMM, 32x32 tile per workgroup (v0: FP64 vector FMAs through LDS tiles).
 //   AMODE 0: A is M x K column-major          AMODE 1: A_op = A^H, A stored K x M
@@ -793,66 +686,13 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
     if (threadIdx.x == 0) dv[KB_V_MISC * it.vstride] = rmax;
 }
 
-__global__ void __launch_bounds__(512) k_hqr(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                               cd* arena, double* varena, cd* mu_out, int* status,
-                                               int smem_bytes, int nsmax, int win_w, MsStats* prof, int count,
-                                               int* queue) {
-    // queue == nullptr: workgroup b solves member perm[b].  Otherwise the workgroups of the launch take
-    // members perm[0], perm[1], ... (largest first) from the queue until it is empty.
-    const DevCtx ctx = make_ctx(smem_bytes);
-    __shared__ int info;
-    __shared__ int next;
-    for (;;) {
-        int idx = blockIdx.x;
-        if (queue) {
-            if (threadIdx.x == 0) next = atomicAdd(queue, 1);
-            __syncthreads();
-            idx = next;
-            __syncthreads();
-        }
-        if ((unsigned)idx >= (unsigned)count) break;
-        const int item = perm[idx];
-        const KbItem it = items[item];
-        cd* Hc = arena + it.off[KB_BUF_H];
-        cd* mu = mu_out + it.line_off;
-        hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, prof ? prof + item : nullptr, win_w);
-        if (threadIdx.x == 0 && info != 0) status[item] |= KB_STAT_EIG_NOCONV;
-        if (!queue) break;
-        __syncthreads();
-    }
-}
-
-// Team variant for large members: workgroup 2t is the chase workgroup of member t, workgroup 2t + 1
-// its helper on another CU (far strip tiles).  Team-major numbering: a team's two workgroups are
-// dispatched together.  The host launches at most as many teams as fit the chip at one workgroup per
-// CU, so every workgroup of the launch is resident; all waits are bounded (abort flag + status bit).
-__global__ void __launch_bounds__(512) k_hqr_team(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                    cd* arena, cd* mu_out, int* status, int smem_bytes,
-                                                    int nsmax, int win_w, TeamCtl* ctl, char* rings, MsStats* prof) {
-    const int team = blockIdx.x >> 1, role = blockIdx.x & 1;
-    const int item = perm[team];
-    const KbItem it = items[item];
-    const DevCtx ctx = make_ctx(smem_bytes);
-    cd* Hc = arena + it.off[KB_BUF_H];
-    Team<DevCtx> tm;
-    tm.ctl = ctl + item;
-    tm.rec_bytes = team_rec_bytes(nsmax, win_w);
-    tm.ring = rings + (size_t)item * KB_TEAM_SLOTS * tm.rec_bytes;
-    tm.g = 0; tm.g_batch = 0; tm.failed = 0;
-    tm.A = HSc1::make(Hc, it.l, it.l);
-    tm.W = win_w; tm.nsmax = nsmax;
-    if (role == 0) {
-        cd* mu = mu_out + it.line_off;
-        __shared__ int info;
-        hqr_eigvals_ms(ctx, it.l, Hc, it.l, mu, &info, nsmax, prof ? prof + item : nullptr, win_w, &tm);
-        if (threadIdx.x == 0 && info != 0) atomicOr(&status[item], KB_STAT_EIG_NOCONV);
-    } else {
-        team_helper_main(ctx, tm);
-    }
-}
-
-// Second-generation QR iteration (kb_hqr2.hpp): double-shift bulges, register-systolic strip replay, window + log
-// in LDS only (two workgroups per CU).  Same launch conventions as k_hqr / k_hqr_team.
+// QR iteration (kb_hqr2.hpp): double-shift bulges, register-systolic strip replay, window + log in LDS.
+// k_hqr2: queue == nullptr: workgroup b solves member perm[b]; otherwise the workgroups of the launch take members
+// perm[0], perm[1], ... (largest first) from the queue until it is empty.
+// k_hqr2_team (large members): workgroup 2t is the chase workgroup of member t, workgroup 2t + 1 its helper on
+// another CU (far strip units).  Team-major numbering: a team's two workgroups are dispatched together.  The host
+// launches at most as many teams as fit the chip at one workgroup per CU, so every workgroup of the launch is
+// resident; all waits are bounded (abort flag + status bit).
 __global__ void __launch_bounds__(512) k_hqr2(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                    cd* arena, cd* mu_out, int* status, int smem_bytes, int nbmax,
                                                    int win_w, MsStats* prof, int count, int* queue) {

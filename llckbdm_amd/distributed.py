@@ -105,7 +105,7 @@ class RcclComm:
         if len(ms):
             status = plan.download_status()
             if np.any(status & (_lib.STAT_SVD_NOCONV | _lib.STAT_EIG_NOCONV)):
-                plan.set_mode(_lib.MODE_SAFE_REPLAY | _lib.MODE_SOLO_QR)
+                plan.set_mode(_lib.MODE_SOLO_QR)
                 try:
                     plan.execute(sync=True)
                 finally:

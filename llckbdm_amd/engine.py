@@ -52,7 +52,7 @@ class BatchResult:
 
 def checked(engine, res, signals, sig_idx, m, l, p, q, dwell, what="KBDM"):
     """The status word as the drop-in contract: members flagged SVD_NOCONV / EIG_NOCONV are solved ONCE more in the
-    conservative modes (stream-dependency replay, solo QR iteration; same process) and patched into `res`; members
+    conservative mode (solo QR iteration: no workgroup teams; same process) and patched into `res`; members
     that are still flagged raise numpy.linalg.LinAlgError as scipy.linalg.svd / scipy.linalg.eig do in the reference
     (kbdm.py:166,192); INVIT_WEAK warns.  Returns `res`."""
     hard = _lib.STAT_SVD_NOCONV | _lib.STAT_EIG_NOCONV
@@ -64,7 +64,7 @@ def checked(engine, res, signals, sig_idx, m, l, p, q, dwell, what="KBDM"):
         signals = np.ascontiguousarray(np.atleast_2d(signals), dtype=np.complex128)
         plan = engine.plan(signals.shape[0], signals.shape[1], sig_idx[bad], m[bad], l[bad], p, q, dwell)
         try:
-            plan.set_mode(_lib.MODE_SAFE_REPLAY | _lib.MODE_SOLO_QR)
+            plan.set_mode(_lib.MODE_SOLO_QR)
             plan.submit(signals)
             again = plan.collect()
         finally:

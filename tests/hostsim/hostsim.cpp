@@ -92,66 +92,24 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
     std::vector<double> d(m), e(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) + 4 * m);
+    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1) + 4 * m);
     hs_bidiag_blocked(ctx, m, A.data(), d.data(), e.data(), tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
-    int info = 0, nb = 0;
-    const char* dcz = getenv("HS_SVD_DC");
-    if (!dcz || atoi(dcz) != 0) {
-        // divide and conquer on (d, e), then L = Q X, R = P Y (what the device does: kb_bdsdc.hpp + real GEMMs)
-        std::vector<double> X((size_t)m * m), Y((size_t)m * m);
-        info = hs_bdsdc(d.data(), e.data(), m, X.data(), s_out, Y.data());
-        cd* Lo = reinterpret_cast<cd*>(L_out);
-        cd* Ro = reinterpret_cast<cd*>(R_out);
-        for (int c = 0; c < m; ++c)
-            for (int r = 0; r < m; ++r) {
-                cd l = czero(), rr = czero();
-                for (int k = 0; k < m; ++k) {
-                    l = l + X[k + (size_t)c * m] * Q[r + (size_t)k * m];
-                    rr = rr + Y[k + (size_t)c * m] * P[r + (size_t)k * m];
-                }
-                Lo[r + (size_t)c * m] = l; Ro[r + (size_t)c * m] = rr;
+    // divide and conquer on (d, e), then L = Q X, R = P Y (what the device does: kb_bdsdc.hpp + real GEMMs)
+    std::vector<double> X((size_t)m * m), Y((size_t)m * m);
+    const int info = hs_bdsdc(d.data(), e.data(), m, X.data(), s_out, Y.data());
+    cd* Lo = reinterpret_cast<cd*>(L_out);
+    cd* Ro = reinterpret_cast<cd*>(R_out);
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < m; ++r) {
+            cd l = czero(), rr = czero();
+            for (int k = 0; k < m; ++k) {
+                l = l + X[k + (size_t)c * m] * Q[r + (size_t)k * m];
+                rr = rr + Y[k + (size_t)c * m] * P[r + (size_t)k * m];
             }
-        return info;
-    }
-    std::vector<RotBatch> hdr(bdsqr_log_batches_cap(m));
-    std::vector<Rot> rot(bdsqr_log_steps_cap(m));
-    bdsqr_gen(ctx, m, d.data(), e.data(), hdr.data(), rot.data(), &nb, &info);
-    bdsqr_apply_ref(m, Q.data(), m, 0, hdr.data(), rot.data(), nb);     // reference replay, sweep by sweep
-    bdsqr_apply_ref(m, P.data(), m, 1, hdr.data(), rot.data(), nb);
-    sort_sv(ctx, m, d.data(), Q.data(), m, P.data(), m, s_out, reinterpret_cast<cd*>(L_out), m,
-            reinterpret_cast<cd*>(R_out), m);
-    return info;
-}
-
-// Same factorisation with the STREAMING replay of the rotation log (bdsqr_stream_lane: register
-// window, the sweeps of a set as a wavefront) instead of the reference replay; `split` > 1 also exercises
-// resuming the replay at a batch boundary (what the device does while the generator is still running).
-int hs_svd_stream(const double* A_in, int m, double* L_out, double* s_out, double* R_out, int split) {
-    std::vector<cd> A(m * m), Q(m * m), P(m * m), UR(m * m), tq(m), tp(m);
-    std::vector<double> d(m), e(m);
-    memcpy(A.data(), A_in, sizeof(cd) * m * m);
-    std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1) + bdsqr_gen_scratch_bytes(m) + 4 * m);
-    hs_bidiag_blocked(ctx, m, A.data(), d.data(), e.data(), tq.data(), tp.data(), UR.data());
-    gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
-    gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
-    int info = 0, nb = 0;
-    std::vector<RotBatch> hdr(bdsqr_log_batches_cap(m));
-    std::vector<Rot> rot(bdsqr_log_steps_cap(m));
-    bdsqr_gen(ctx, m, d.data(), e.data(), hdr.data(), rot.data(), &nb, &info);
-    if (split < 1) split = 1;
-    for (int which = 0; which < 2; ++which) {
-        double* X = reinterpret_cast<double*>(which == 0 ? Q.data() : P.data());
-        for (int vl = 0; vl < 2 * m; ++vl)
-            for (int part = 0; part < split; ++part) {
-                const int b0 = (int)((long long)nb * part / split), b1 = (int)((long long)nb * (part + 1) / split);
-                bdsqr_stream_lane(X + vl, true, (size_t)m, which, hdr.data(), rot.data(), b0, b1);
-            }
-    }
-    sort_sv(ctx, m, d.data(), Q.data(), m, P.data(), m, s_out, reinterpret_cast<cd*>(L_out), m,
-            reinterpret_cast<cd*>(R_out), m);
+            Lo[r + (size_t)c * m] = l; Ro[r + (size_t)c * m] = rr;
+        }
     return info;
 }
 
@@ -173,7 +131,7 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
     HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hess_panel_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n) +
-                                      hqr_win_scratch_bytes(8, 60, 1));
+                                      hqr2_scratch_bytes(KB2_WIN_DEV));
     {   // blocked Hessenberg reduction as the kernels sequence it: panels + updates + tail
         const int npan = bidiag_num_panels(n);
         std::vector<cd> Yp((size_t)n * KB_NB), Zp((size_t)n * KB_NB), VTp((size_t)n * KB_NB), MTp(KB_NB * KB_NB);
@@ -203,7 +161,7 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     }
     int info = 0, weak = 0;
     cd* mu = reinterpret_cast<cd*>(mu_out);
-    hqr_eigvals_ms(ctx, n, Hc.data(), n, mu, &info, 8, nullptr, 60);   // the variant the k_hqr kernel runs
+    hqr2_eigvals(ctx, n, Hc.data(), n, mu, &info, KB2_NBMAX, KB2_WIN_DEV);   // what k_hqr2 runs
     invit<HostCtx, 4096>(ctx, n, W.data(), n, mu, hnorm, X.data(), n, 1, &weak);
     // P = Qh * X
     cd* P = reinterpret_cast<cd*>(P_out);
@@ -216,23 +174,6 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     return info | (weak ? 4 : 0);
 }
 
-
-// eigenvalues only, multishift variant; stats = {intervals, batches, single_sweeps}
-int hs_eigvals_ms(const double* W_in, int n, int nsmax, int win_w, double* mu_out, long long* stats_out) {
-    std::vector<cd> W(n * n), Hc(n * n), Ht(n * n), th(n);
-    memcpy(W.data(), W_in, sizeof(cd) * n * n);
-    std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_win_scratch_bytes(nsmax > KB_MS_NSMAX ? KB_MS_NSMAX : nsmax, win_w > 0 ? win_w : 8, 1));
-    gehd2(ctx, n, W.data(), n, th.data());
-    hess_copy(ctx, n, W.data(), n, Hc.data(), n);
-    int info = 0;
-    MsStats st;
-    memset(&st, 0, sizeof(st));
-    hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st, win_w);
-    if (stats_out) { stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps;
-                     stats_out[4] = st.ab_calls; stats_out[5] = st.ab_fail; stats_out[6] = st.ab_iters; }
-    return info;
-}
 
 // The Aberth / Hyman small eigenvalue solver on its own: T upper Hessenberg n x n (column-major), z out.
 // Returns the solver's verdict (1 = converged).
@@ -247,38 +188,6 @@ int hs_aberth(const double* T_in, int n, double* z_out) {
                              : aberth_eigs(wc, n, T.data(), n, z.data(), U.data(), D.data(), zw.data(), 40);
     memcpy(z_out, z.data(), sizeof(cd) * n);
     return ok ? 1 : 0;
-}
-
-// Same, through the workgroup-TEAM code path: the helper workgroup's share of every record is run
-// inline (sequentially) by the one host thread, so tile partition, record layout and bookkeeping of
-// the protocol are exercised; the waits themselves are device-only.
-int hs_eigvals_team(const double* W_in, int n, int nsmax, int win_w, double* mu_out, long long* stats_out) {
-    std::vector<cd> W(n * n), Hc(n * n), th(n);
-    memcpy(W.data(), W_in, sizeof(cd) * n * n);
-    std::vector<char> arena;
-    if (nsmax > KB_MS_NSMAX) nsmax = KB_MS_NSMAX;
-    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hqr_win_scratch_bytes(nsmax, win_w > 0 ? win_w : 8, 1));
-    gehd2(ctx, n, W.data(), n, th.data());
-    hess_copy(ctx, n, W.data(), n, Hc.data(), n);
-    int info = 0;
-    MsStats st;
-    memset(&st, 0, sizeof(st));
-    TeamCtl ctl;
-    memset(&ctl, 0, sizeof(ctl));
-    Team<HostCtx> tm;
-    tm.ctl = &ctl;
-    tm.rec_bytes = team_rec_bytes(nsmax, win_w);
-    std::vector<char> ring((size_t)KB_TEAM_SLOTS * tm.rec_bytes);
-    tm.ring = ring.data();
-    tm.g = 0; tm.g_batch = 0; tm.failed = 0;
-    tm.A = HSc1::make(Hc.data(), n, n);
-    tm.W = win_w; tm.nsmax = nsmax;
-    hqr_eigvals_ms(ctx, n, Hc.data(), n, reinterpret_cast<cd*>(mu_out), &info, nsmax, &st, win_w, &tm);
-    if (stats_out) {
-        stats_out[0] = st.intervals; stats_out[1] = st.batches; stats_out[2] = st.single_sweeps; stats_out[3] = st.small_steps;
-        stats_out[4] = ctl.published; stats_out[5] = ctl.all_done; stats_out[6] = ctl.done; stats_out[7] = ctl.near_done;
-    }
-    return info;
 }
 
 // Debug trace of the second-generation iteration: one line per window step (geometry + a checksum of H) into the

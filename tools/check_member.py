@@ -13,7 +13,7 @@ res = eng.solve(sigs, [0], [m], None, p=1, q=0.0, dwell=datasets.DWELL)
 want, info, mu_ref = O.kbdm(sigs[0], datasets.DWELL, m=m, normalizer="gemm", return_mu=True) if "return_mu" in O.kbdm.__code__.co_varnames else (*O.kbdm(sigs[0], datasets.DWELL, m=m, normalizer="gemm"), None)
 got = res.line_list(0)
 k, w = canonical(got[keep_mask(got)]), canonical(O.filter_samples(want))
-print("HQR_V", os.environ.get("KBDM_HQR_V", "2"), "m", m, "status", int(res.status[0]), "kept", len(k), len(w))
+print("m", m, "status", int(res.status[0]), "kept", len(k), len(w))
 if len(k) == len(w):
     rel = np.abs(k[:, :3] - w[:, :3]) / np.abs(w[:, :3])
     strong = w[:, 0] > 1e-4

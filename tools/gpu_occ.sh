@@ -18,7 +18,7 @@ for d in ("occ", "occ2"):
             k = (fn, r["Dispatch_Id"])
             if k not in seen: seen.add(k); calls[name] += 1
     ctrs = sorted({c for v in acc.values() for c in v})
-    nens = max(1, calls.get("k_bdsqr_sort", 2) // 2)
+    nens = max(1, calls.get("k_dc_sv", 2) // 2)
     print(d, "ensembles:", nens, "counters per ensemble (G):", ctrs)
     key = "SQ_INSTS_VALU"
     for name, v in sorted(acc.items(), key=lambda kv: -kv[1][key])[:22]:
