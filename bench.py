@@ -350,7 +350,19 @@ def main():
                         run_api_loop(eng, w, fl_o, fl_o, resident=False)                     # plans + warm-up
                         to = run_api_loop(eng, w, steps_o, fl_o, resident=False)
                         chk = eng.submit(*w[0][:3], w[0][2], p=1, q=0.0, dwell=DWELL).result(check=False)
-                        others[name] = {"workload": WORKLOADS[name], "value": len(w[0][2]) * steps_o / to, "unit": "solves/s",
+                        hk = None
+                        if name == "C3":
+                            # the Hankel build on a launch that fills the chip (the C2 launches are 35-55 us: launch-latency
+                            # bound): lane 0's members of this run, algorithmic bytes 16 m^2 written + 16 (2m - 1) read per member
+                            h = eng.submit(*w[0][:3], w[0][2], p=1, q=0.0, dwell=DWELL)
+                            h.result(check=False)
+                            n0h = h.plan.lane0_members()
+                            mm = sorted((int(x) for x in w[0][2]), reverse=True)[:n0h]
+                            hb = sum(16.0 * x * x + 16.0 * (2 * x - 1) for x in mm)
+                            ms_h = h.plan.stage_ms()["k_hankel"]
+                            hk = {"kernel": "k_hankel", "members": n0h, "bytes": hb, "ms": ms_h, "GBps": hb / (ms_h * 1e-3) / 1e9,
+                                  "frac_of_hbm_peak": hb / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        others[name] = {"workload": WORKLOADS[name], "value": len(w[0][2]) * steps_o / to, "unit": "solves/s", "hankel_build": hk,
                                         "ms_per_step": 1e3 * to / steps_o, "steps": steps_o, "ensembles_in_flight": fl_o,
                                         "members": int(len(w[0][2])), "members_ok": int((chk.status == 0).sum()),
                                         "timed": "host -> host through Engine.submit"}

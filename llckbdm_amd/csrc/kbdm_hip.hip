@@ -104,7 +104,6 @@ struct kbdm_ctx {
                           // 0 = one workgroup per member, N = fixed
     int gen_wy = 1;       // explicit Q / P / Qh of large members by blocked compact-WY accumulation on MFMA (0: k_gen for all)
     int blocked = 1;      // blocked (panel + MFMA update) reductions; 0: unblocked kernels only (debugging)
-    int stream_wpb = 1;   // KBDM_STREAM_WPB: row blocks (wavefronts) per workgroup of the rotation replay
     int bidiag_fused = 0; // KBDM_BIDIAG_FUSED=1: one pass over the trailing matrix per panel column (members up to 512 rows)
     int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
     int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
@@ -705,7 +704,6 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->gen_wy = env_int("KBDM_GEN_WY", c->gen_wy);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
     c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
-    c->stream_wpb = env_int("KBDM_STREAM_WPB", c->stream_wpb);
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
     c->win_hqr2 = KB2_WIN_DEV;                       // the device chase is compiled for this window
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
@@ -1388,7 +1386,11 @@ int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int
         if (min_samples[f] < 1 || min_samples[f] > n) return fail(KBDM_E_INVALID, "min_samples out of range");
         K = std::max(K, (int)min_samples[f]);
     }
-    const size_t lds = ((size_t)K * KB_KNN_TPB + (size_t)KB_KNN_TPB * KB_SIL_MAXDIM) * sizeof(double);
+    // threads (= samples) per workgroup of the k-nearest-neighbour pass: as many as keep K running lists in LDS
+    int tpb = KB_KNN_TPB;
+    auto knn_lds = [&](int t) { return ((size_t)K * t + (size_t)t * KB_SIL_MAXDIM) * sizeof(double); };
+    while (tpb > 8 && knn_lds(tpb) > (size_t)LDS_MAX - 64) tpb >>= 1;
+    const size_t lds = knn_lds(tpb);
     if (lds > (size_t)LDS_MAX - 64) return fail(KBDM_E_NOMEM, "min_samples too large for the k-nearest-neighbour kernel");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_dist), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -1408,7 +1410,7 @@ int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int
         }
         hipMemcpyAsync(d_x, X, sizeof(double) * n * dim, hipMemcpyHostToDevice, st);
         hipMemcpyAsync(d_ms, min_samples, sizeof(int) * nfits, hipMemcpyHostToDevice, st);
-        hipLaunchKernelGGL(k_knn_dist, dim3((n + KB_KNN_TPB - 1) / KB_KNN_TPB), dim3(KB_KNN_TPB), lds, st, d_x, n, dim, K, d_knn);
+        hipLaunchKernelGGL(k_knn_dist, dim3((n + tpb - 1) / tpb), dim3(tpb), lds, st, d_x, n, dim, K, d_knn);
         hipLaunchKernelGGL(k_prim_mst, dim3(nfits), dim3(1024), 0, st, d_x, n, dim, K, d_knn, d_ms, d_best, d_core, d_src, d_edges);
         hipMemcpyAsync(edges.data(), d_edges, sizeof(KbEdge) * edges.size(), hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "hdbscan kernels failed"); break; }

@@ -120,26 +120,29 @@ namespace kb {
 // k_knn_dist: for every sample the K smallest distances to the samples (itself included, so entry 0 is 0),
 // ascending: knn[i * K + q].  One thread per sample; the running top-K of a thread lives in LDS laid out
 // [q][thread] (conflict-free); candidates stream through registers from an LDS tile; a candidate is inserted only
-// if it beats the current K-th best (after the first few tiles that is rare).
+// if it beats the current K-th best (after the first few tiles that is rare).  The workgroup size is chosen by the
+// host so that K lists fit the LDS: 64 threads up to K = 300, then 32 / 16 / 8 (K up to ~2300: every min_samples of
+// a 1001-member m_range stays on the GPU).
 #define KB_KNN_TPB 64
 __global__ void __launch_bounds__(KB_KNN_TPB) k_knn_dist(const double* __restrict__ xs, int n, int dim, int K,
                                                           double* __restrict__ knn) {
     extern __shared__ double kb_knn_lds[];
-    double* top = kb_knn_lds;                                  // K x TPB
-    double* tile = kb_knn_lds + (size_t)K * KB_KNN_TPB;        // TPB x MAXDIM
+    const int tpb = blockDim.x;
+    double* top = kb_knn_lds;                                  // K x tpb
+    double* tile = kb_knn_lds + (size_t)K * tpb;               // tpb x MAXDIM
     const int t = threadIdx.x;
-    const int i = blockIdx.x * KB_KNN_TPB + t;
+    const int i = blockIdx.x * tpb + t;
     const bool live = i < n;
     double xi[KB_SIL_MAXDIM];
 #pragma unroll
     for (int d = 0; d < KB_SIL_MAXDIM; ++d) xi[d] = (live && d < dim) ? xs[(size_t)i * dim + d] : 0.0;
     const double inf = 1.79769313486231570815e308;
-    for (int q = 0; q < K; ++q) top[q * KB_KNN_TPB + t] = inf;
+    for (int q = 0; q < K; ++q) top[q * tpb + t] = inf;
     double kth = inf;                                          // current K-th best of this thread
-    for (int jb = 0; jb < n; jb += KB_KNN_TPB) {
-        const int cnt = (n - jb < KB_KNN_TPB) ? n - jb : KB_KNN_TPB;
+    for (int jb = 0; jb < n; jb += tpb) {
+        const int cnt = (n - jb < tpb) ? n - jb : tpb;
         __syncthreads();
-        for (int idx = t; idx < cnt * dim; idx += KB_KNN_TPB) tile[idx] = xs[(size_t)jb * dim + idx];
+        for (int idx = t; idx < cnt * dim; idx += tpb) tile[idx] = xs[(size_t)jb * dim + idx];
         __syncthreads();
         if (live) {
             for (int j = 0; j < cnt; ++j) {
@@ -151,15 +154,15 @@ __global__ void __launch_bounds__(KB_KNN_TPB) k_knn_dist(const double* __restric
                 if (dj < kth) {
                     // insert into the ascending list (shift the tail down by one)
                     int q = K - 1;
-                    while (q > 0 && top[(q - 1) * KB_KNN_TPB + t] > dj) { top[q * KB_KNN_TPB + t] = top[(q - 1) * KB_KNN_TPB + t]; --q; }
-                    top[q * KB_KNN_TPB + t] = dj;
-                    kth = top[(K - 1) * KB_KNN_TPB + t];
+                    while (q > 0 && top[(q - 1) * tpb + t] > dj) { top[q * tpb + t] = top[(q - 1) * tpb + t]; --q; }
+                    top[q * tpb + t] = dj;
+                    kth = top[(K - 1) * tpb + t];
                 }
             }
         }
     }
     if (live)
-        for (int q = 0; q < K; ++q) knn[(size_t)i * K + q] = top[q * KB_KNN_TPB + t];
+        for (int q = 0; q < K; ++q) knn[(size_t)i * K + q] = top[q * tpb + t];
 }
 
 // k_prim_mst: one workgroup per fit (value of min_samples): Prim's algorithm from sample 0 over the complete graph

@@ -49,8 +49,8 @@ class ClusteringResult:
 
 
 MIN_CLUSTER_SIZE = 5        # hdbscan.HDBSCAN's default, which the reference does not change (llckbdm.py:280)
-GPU_SWEEP_MAX_K = 300       # the k-nearest-neighbour pass of `Engine.hdbscan_sweep` keeps a lane's K candidates in LDS
-                            # ((64 K + 512) doubles per workgroup): larger min_samples go to scikit-learn's HDBSCAN
+GPU_SWEEP_MAX_K = 2300      # the k-nearest-neighbour pass of `Engine.hdbscan_sweep` keeps a thread's K candidates in LDS and
+                            # shrinks its workgroups from 64 to 8 threads as K grows; 8 K + 64 doubles must fit 160 KB
 
 
 def _fit_labels(transformed_samples, min_samples, clusterer, engine):
@@ -92,7 +92,7 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None, clusterer="g
         if on_gpu:
             got, _ = eng.hdbscan_sweep(transformed_line_list, on_gpu, MIN_CLUSTER_SIZE)
             labels_all.update(zip(on_gpu, got))
-        for k in fits:                       # ensembles of more than GPU_SWEEP_MAX_K members (e.g. config 4's m_range)
+        for k in fits:                       # (beyond any m_range of BASELINE.json: scikit-learn on the host)
             if k > GPU_SWEEP_MAX_K:
                 labels_all[k] = _fit_labels(transformed_line_list, k, "sklearn", eng)
     for min_samples in sweep:

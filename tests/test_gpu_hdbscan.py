@@ -36,6 +36,94 @@ def test_sweep_matches_sklearn(eng):
             assert abs(int((ref == -1).sum()) - int((labels[f] == -1).sum())) <= max(3, len(X) // 200)
 
 
+def _canon(labels):
+    """Relabel clusters in order of first appearance (noise stays -1): equal partitions <=> equal arrays."""
+    out, seen = np.full(len(labels), -1, dtype=np.int64), {}
+    for i, v in enumerate(labels):
+        if v >= 0:
+            out[i] = seen.setdefault(int(v), len(seen))
+    return out
+
+
+def test_tie_free_inputs_give_scikit_learns_labels_exactly(eng):
+    """With min_samples <= 2 the mutual-reachability distance IS the Euclidean distance (a sample's core distance is
+    at most its distance to any other sample), so random points have no ties, the minimum spanning tree and the
+    single-linkage hierarchy are unique, and the labels must equal scikit-learn's - as arrays, not up to a Rand index."""
+    from sklearn.cluster import HDBSCAN
+    rng = np.random.default_rng(5)
+    for n, nc, spread, noise in ((300, 4, 0.1, 30), (1500, 12, 0.2, 300), (700, 3, 0.5, 0), (2500, 30, 0.15, 500)):
+        X = _data(rng, n, nc, spread, noise)
+        labels, ncl = eng.hdbscan_sweep(X, [1, 2])
+        for f, k in enumerate((1, 2)):
+            ref = HDBSCAN(min_samples=k, min_cluster_size=5, copy=True).fit(X).labels_
+            assert np.array_equal(_canon(labels[f]), _canon(ref)), (n, k)
+            assert np.array_equal(labels[f], ref), (n, k)          # the numbering convention matches as well
+
+
+def _prim_reference(X, k):
+    """The documented tie rule, restated in numpy: core distances from a full sort, Prim from sample 0 over the
+    mutual-reachability graph, strict '<' relaxation, the closest outside sample with the LOWEST index next."""
+    n = len(X)
+    D = np.sqrt(((X[:, None, :] - X[None, :, :]) ** 2).sum(-1))
+    core = np.sort(D, axis=1)[:, k - 1]
+    best, src, intree = np.full(n, np.inf), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=bool)
+    intree[0] = True
+    cur, edges = 0, []
+    for _ in range(n - 1):
+        w = np.maximum(D[cur], np.maximum(core, core[cur]))
+        upd = (~intree) & (w < best)
+        best[upd], src[upd] = w[upd], cur
+        cand = np.where(intree, np.inf, best)
+        nxt = int(np.argmin(cand))                                # argmin: first (lowest) index among ties
+        edges.append((int(src[nxt]), nxt, float(best[nxt])))
+        intree[nxt] = True
+        cur = nxt
+    return edges
+
+
+def test_documented_tie_rule_on_inputs_full_of_ties(eng):
+    """A lattice with duplicated points: almost every mutual-reachability weight is tied.  The GPU sweep must follow
+    the rule kbdm_cluster.hpp documents (Prim from sample 0, lowest index among equal candidates, dendrogram edges in
+    stable weight order): its labels equal the host tree code run on a numpy Prim that implements exactly that rule -
+    and they are the same on every run."""
+    from llckbdm_amd import _lib
+    g = np.stack(np.meshgrid(np.arange(6.0), np.arange(6.0), np.arange(3.0), [0.0]), -1).reshape(-1, 4)
+    X = np.concatenate([g, g[:40] + 10.0, g[:15]])
+    ks = [1, 3, 6]
+    labels, _ = eng.hdbscan_sweep(X, ks)
+    again, _ = eng.hdbscan_sweep(X, ks)
+    assert np.array_equal(labels, again)
+    lib = _lib.load()
+    for f, k in enumerate(ks):
+        e = _prim_reference(X, k)
+        a = np.array([x[0] for x in e], dtype=np.int32)
+        b = np.array([x[1] for x in e], dtype=np.int32)
+        w = np.array([x[2] for x in e], dtype=np.float64)
+        ref = np.empty(len(X), dtype=np.int32)
+        lib.kbdm_hdbscan_labels_from_mst(len(X), _lib.ptr(a), _lib.ptr(b), _lib.ptr(w), 5, _lib.ptr(ref))
+        assert np.array_equal(labels[f], ref), k
+
+
+def test_large_min_samples_stay_on_the_gpu(eng):
+    """min_samples beyond 300 (an m_range of more than 301 members, e.g. BASELINE config 4's 1001): the k-nearest-
+    neighbour pass shrinks its workgroups instead of leaving the GPU; core distances checked through the labels of
+    the documented rule."""
+    from llckbdm_amd import _lib
+    rng = np.random.default_rng(8)
+    X = _data(rng, 1400, 3, 0.3, 100)
+    ks = [301, 700, 1000]
+    labels, ncl = eng.hdbscan_sweep(X, ks)
+    lib = _lib.load()
+    for f, k in enumerate(ks):
+        e = _prim_reference(X, k)
+        a = np.array([x[0] for x in e], dtype=np.int32)
+        b = np.array([x[1] for x in e], dtype=np.int32)
+        w = np.array([x[2] for x in e], dtype=np.float64)
+        ref = np.empty(len(X), dtype=np.int32)
+        lib.kbdm_hdbscan_labels_from_mst(len(X), _lib.ptr(a), _lib.ptr(b), _lib.ptr(w), 5, _lib.ptr(ref))
+        assert np.array_equal(labels[f], ref), k
+
+
 def test_sweep_degenerate_inputs(eng):
     rng = np.random.default_rng(2)
     X = rng.standard_normal((40, 4))

@@ -66,6 +66,41 @@ def test_cluster_membership_identical_for_gpu_and_oracle_lines(eng, clusterer):
     assert max(len(set(r.tolist()) - {-1}) for r in g_lab) >= 10       # the sweep does find the peaks' clusters
 
 
+def test_cluster_membership_at_c2_scale(eng):
+    """The same check at the scale the north star quotes (BASELINE config 2: 151 members, N = 2048, ~19 k pooled
+    lines, all 150 fits of the reference's sweep llckbdm.py:104): GPU-produced and oracle-produced line lists go
+    through the same clusterer (the built-in sweep) and must give identical membership indices for every min_samples.
+    The oracle members are computed on the host cores of the box (one process per core)."""
+    import subprocess
+    import sys
+    import tempfile
+    from llckbdm_amd import datasets
+    from llckbdm_amd.llckbdm import MIN_CLUSTER_SIZE
+    from llckbdm_amd.sampling import sample_kbdm
+    sigs, _, ms = datasets.config2(seed=0)
+    sig = sigs[0]
+    g_l, _ = sample_kbdm(sig, DWELL, ms.tolist(), p=1, l=None, q=0, engine=eng)
+    with tempfile.TemporaryDirectory() as td:       # the oracle in a child interpreter (never fork a process that holds a HIP context)
+        np.save(os.path.join(td, "sig.npy"), sig)
+        np.save(os.path.join(td, "ms.npy"), ms)
+        subprocess.run([sys.executable, os.path.join(ROOT, "tests", "oracle_pool.py"), os.path.join(td, "sig.npy"),
+                        os.path.join(td, "ms.npy"), os.path.join(td, "out.npz")], check=True, timeout=900)
+        with np.load(os.path.join(td, "out.npz")) as z:
+            o_l = [z[f"m{int(m)}"] for m in ms]
+    o_l = [x for x in o_l if len(x)]
+    assert [len(a) for a in g_l] == [len(b) for b in o_l]               # same kept lines, member by member
+    g_pool, g_x = _pooled_features(g_l, DWELL)
+    o_pool, o_x = _pooled_features(o_l, DWELL)
+    assert g_x.shape == o_x.shape and len(g_x) > 15000
+    assert np.abs(g_x - o_x).max() < 1e-6
+    sweep = list(range(1, len(ms)))                                     # 150 fits
+    g_lab, g_n = eng.hdbscan_sweep(g_x, sweep, MIN_CLUSTER_SIZE)
+    o_lab, o_n = eng.hdbscan_sweep(o_x, sweep, MIN_CLUSTER_SIZE)
+    bad = [(k, int((a != b).sum())) for k, a, b in zip(sweep, g_lab, o_lab) if not np.array_equal(a, b)]
+    assert not bad, f"membership differs for {len(bad)} of {len(sweep)} fits: {bad[:8]}"
+    assert np.array_equal(g_n, o_n) and g_n.max() >= 16
+
+
 def _solve_case(eng, g, name):
     from llckbdm_amd.kbdm import kbdm
     m, l, p = (int(x) for x in g[f"{name}__meta"])
