@@ -113,6 +113,9 @@ const char* kbdm_stage_name(int stage);
  * each an in-order pipeline on its own HIP stream).  The stage timers above are lane 0's: the
  * critical path.  Returns the number of members (the largest ones) that lane 0 holds. */
 int kbdm_plan_lane0_members(const kbdm_plan* plan);
+/* Members of the last run whose eigenvalues came from the QR iteration because the divide-and-conquer Ehrlich-Aberth
+ * path declined them (negligible subdiagonal, a root that did not settle, power-sum check); waits for the plan. */
+int kbdm_plan_eig_fallbacks(kbdm_plan* plan);
 
 /* ---- multi-GPU: the sharded ensemble (reference loop sampling.py:52-70, members dealt over the ranks) ends in ONE
  * variable-length gather of every rank's packed results over xGMI.  The library binds librccl.so itself (dlopen); the

@@ -1,0 +1,354 @@
+// gfx950 kernels of the divide-and-conquer Ehrlich-Aberth eigenvalue solver (algorithm: kb_aberth.hpp; the fast path
+// of the reference's scipy.linalg.eig at kbdm.py:192, eigenvalues only; eigenvectors follow by inverse iteration).
+//
+//   k_ab_leaf    one wavefront per (member, leaf <= 32 rows): the small solver of kb_hqr2.hpp (hqr2_shifts); workgroup 0
+//                of a member also scans the subdiagonal (a negligible entry sends the member to the QR iteration)
+//   k_ab_iter    one workgroup per (member, node of the step's level, tile of 64 roots): ONE Aberth iteration of those
+//                roots: the repulsion sums, Hyman's recurrence for the 64 roots and their derivatives as a blocked
+//                product H X (FP64 MFMA for the part of a 32-row block that multiplies finished rows, a two-wavefront
+//                recurrence for the 32 x 32 triangle), the update.  Launched KB_AB_BUDGET times per level; a tile
+//                whose roots have all settled only copies them through.
+//   k_ab_finish  per member: every root settled? power sums against trace(H), trace(H^2); writes mu or flags the
+//                member for the QR iteration (k_hqr2 then runs for flagged members only)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kb_aberth.hpp"
+#include "kbdm_device.h"
+
+// (kb_smem, make_ctx, kb_d4 come from kbdm_kernels.hpp, which includes this file after kb_hqr2.hpp)
+
+constexpr int KB_AB_KC = 8;                     // k per staged chunk of the block product
+constexpr int KB_AB_PA = 40;                    // LDS pitch (doubles) of the H chunk rows  (32 rows + pad)
+constexpr int KB_AB_PB = 136;                   // LDS pitch (doubles) of the panel chunk rows (128 columns + pad)
+
+struct AbLds {                                  // dynamic LDS of k_ab_iter
+    double sa[2][2][KB_AB_KC][KB_AB_PA];        // [buffer][re|im][k][row]       H chunk
+    double sb[2][2][KB_AB_KC][KB_AB_PB];        // [buffer][re|im][k][column]    panel chunk
+    kb::cd bf[KB_AB_BLK][2 * KB_AB_TILE];       // block rows x 128 columns: G, then the finished rows
+    kb::cd ht[KB_AB_BLK][KB_AB_BLK + 1];        // the block's triangle of H (row k, column j), padded
+    kb::cd inv[KB_AB_BLK];                      // 1 / H[k, k-1]
+    kb::cd prow[2 * KB_AB_TILE];                // the finished row above the block (x_{k_hi}, y_{k_hi})
+    kb::cd z[KB_AB_TILE];
+    kb::cd S[KB_AB_TILE];
+    double part[4][KB_AB_TILE][2];
+    int flags[8];
+};
+
+__device__ __forceinline__ kb::AbWs ab_item_ws(const kb::KbItem& it, double* dcarena) { return kb::ab_ws(dcarena + it.dc_off, it.l); }
+
+// column of the panel that holds root r's x (which = 0) / derivative (which = 1): a wavefront owns 32 roots with both
+__device__ __forceinline__ int ab_col(int r, int which) { return (r >> 5) * 64 + which * 32 + (r & 31); }
+
+__global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ items, const int* __restrict__ perm, kb::cd* arena,
+                                                 double* dcarena, int* needqr, int smem_bytes) {
+    using namespace kb;
+    const int item = perm[blockIdx.y];
+    const KbItem it = items[item];
+    const int l = it.l, D = ab_depth(l);
+    if ((int)blockIdx.x >= (1 << D)) return;
+    const DevCtx ctx = make_ctx(smem_bytes);
+    const cd* H = arena + it.off[KB_BUF_H];
+    const AbWs ws = ab_item_ws(it, dcarena);
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0) {                      // the subdiagonal scan and the reset of the member's flags
+        int bad = 0;
+        for (int k = 1 + t; k < l; k += 64)
+            if (ab_negligible_sub(H[k + (size_t)(k - 1) * l], H[k + (size_t)k * l], H[(k - 1) + (size_t)(k - 1) * l])) bad = 1;
+        bad = ctx.block_max(bad);
+        if (t == 0 && bad) atomicOr(&needqr[item], 1);
+    }
+    const AbNode nd = ab_node(l, D, blockIdx.x);
+    const int n = nd.n;
+    cd* S = reinterpret_cast<cd*>(ctx.scratch());
+    cd* sh = S + KB_AB_LEAF * KB_AB_LEAF;
+    cd* aws = sh + KB_AB_LEAF;
+    int* sinfo = reinterpret_cast<int*>(aws + 2 * KB_AB_LEAF * KB_AB_LEAF + 2 * KB_AB_LEAF);
+    for (int idx = t; idx < n * n; idx += 64) {
+        const int r = idx % n, c = idx / n;
+        S[r + c * n] = (r <= c + 1) ? H[(nd.a + r) + (size_t)(nd.a + c) * l] : czero();
+    }
+    if (t == 0) *sinfo = 0;
+    ctx.sync();
+    if (n == 1) { if (t == 0) sh[0] = S[0]; }
+    else if (n == 2) { if (t == 0) eig2x2(S[0], S[2], S[1], S[3], sh[0], sh[1]); }
+    else hqr2_shifts(ctx, n, S, sh, aws, sinfo, (MsStats*)nullptr);
+    ctx.sync();
+    for (int r = t; r < n; r += 64) {
+        ws.z[0][nd.a + r] = sh[r];
+        ws.conv[nd.a + r] = 1;
+        ws.lastc[nd.a + r] = 0.0;
+    }
+    if (t == 0 && *sinfo != 0) atomicOr(&needqr[item], 1);
+}
+
+// grid (tiles * nodes of the deepest level of this step, members); block 256; dynamic LDS sizeof(AbLds)
+__global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                  const kb::cd* __restrict__ arena, const double* __restrict__ varena, double* dcarena,
+                                                  const int* __restrict__ needqr, int step, int iter) {
+    using namespace kb;
+    const int item = perm[blockIdx.y];
+    if (needqr[item]) return;
+    const KbItem it = items[item];
+    const int l = it.l, depth = ab_depth(l) - 1 - step;
+    if (depth < 0) return;
+    const int Tl = (ab_level_nmax(l, depth) + KB_AB_TILE - 1) / KB_AB_TILE;
+    const int idx = blockIdx.x / Tl, tile = blockIdx.x % Tl;
+    if (idx >= (1 << depth)) return;
+    const AbNode nd = ab_node(l, depth, idx);
+    const int n = nd.n, a0 = nd.a;
+    if (tile * KB_AB_TILE >= n) return;
+    const int r0 = tile * KB_AB_TILE;                       // first root of this tile (local to the node)
+    const int nr = (n - r0 < KB_AB_TILE) ? n - r0 : KB_AB_TILE;
+    AbLds& L = *reinterpret_cast<AbLds*>(kb_smem);
+    const AbWs ws = ab_item_ws(it, dcarena);
+    const int bin = (step * KB_AB_BUDGET + iter) & 1;
+    const cd* zin = ws.z[bin] + a0;
+    cd* zout = ws.z[bin ^ 1] + a0;
+    const cd* H = arena + it.off[KB_BUF_H];
+    const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
+    const int t = threadIdx.x;
+    // ---- this tile's roots; the first iteration of a level separates the starting values and re-opens every root
+    if (t == 0) L.flags[0] = 0;
+    __syncthreads();
+    if (t < KB_AB_TILE) {
+        cd z = mk(0.0, 0.0);
+        int cv = 1;
+        if (t < nr) {
+            z = zin[r0 + t];
+            cv = ws.conv[a0 + r0 + t];
+            if (iter == 0) { z = ab_perturb(z, a0 + r0 + t, hnorm); cv = 0; }
+            if (!cv) L.flags[0] = 1;
+        }
+        L.z[t] = z;
+        L.flags[1 + 0] = 0;
+        if (t < nr && cv) zout[r0 + t] = z;                 // settled roots are carried through
+    }
+    __syncthreads();
+    if (!L.flags[0]) return;                                // every root of the tile has settled
+    // ---- repulsion sums S_i = sum_{j != i} 1 / (z_i - z_j) over the node (four threads per root)
+    {
+        const int i = t & 63, q = t >> 6;
+        double sx = 0.0, sy = 0.0;
+        if (i < nr) {
+            const cd zi = L.z[i];
+            for (int j = q; j < n; j += 4) {
+                if (j == r0 + i) continue;
+                cd zj = zin[j];
+                if (iter == 0) zj = ab_perturb(zj, a0 + j, hnorm);
+                const cd d = zi - zj;
+                const double den = d.x * d.x + d.y * d.y;
+                sx += d.x / den; sy -= d.y / den;
+            }
+        }
+        L.part[q][i][0] = sx; L.part[q][i][1] = sy;
+    }
+    __syncthreads();
+    if (t < KB_AB_TILE)
+        L.S[t] = mk((L.part[0][t][0] + L.part[1][t][0]) + (L.part[2][t][0] + L.part[3][t][0]),
+                    (L.part[0][t][1] + L.part[1][t][1]) + (L.part[2][t][1] + L.part[3][t][1]));
+    // ---- Hyman's recurrence, rows n-1 .. 0, blocks of 32 rows.  Panel P[row][128] in global memory.
+    const int Tlrows = Tl;
+    cd* P = ws.panel + ((size_t)a0 * Tlrows + (size_t)tile * n) * (2 * KB_AB_TILE);
+    const int wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    if (t < 2 * KB_AB_TILE) {                               // row n-1: x = 1, y = 0
+        const int c = t, which = (c >> 5) & 1;
+        const cd v = which ? czero() : mk(1.0, 0.0);
+        P[(size_t)(n - 1) * (2 * KB_AB_TILE) + c] = v;
+        L.prow[c] = v;
+    }
+    __syncthreads();
+    int k_hi = n - 1;
+    while (k_hi >= 0) {
+        const int kb0 = (k_hi - (KB_AB_BLK - 1) > 0) ? k_hi - (KB_AB_BLK - 1) : 0;
+        const int M = k_hi - kb0 + 1;
+        // -- the block's triangle of H and the reciprocal subdiagonals
+        for (int e = t; e < KB_AB_BLK * KB_AB_BLK; e += 256) {
+            const int r = e & 31, j = e >> 5;
+            L.ht[r][j] = (r < M && j < M && j >= r - 1 && j >= 0) ? H[(a0 + kb0 + r) + (size_t)(a0 + kb0 + j) * l] : czero();
+        }
+        if (t < KB_AB_BLK) {
+            const int k = kb0 + t;
+            L.inv[t] = (t < M && k >= 1) ? ab_recip(H[(a0 + k) + (size_t)(a0 + k - 1) * l]) : czero();
+        }
+        // -- G[k] = sum_{j = k_hi}^{n-1} H[k, j] P[j, :]   (rows k of the block x 128 columns, MFMA)
+        kb_d4 acc_re[2][2], acc_im[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) { acc_re[x][y] = (kb_d4){0, 0, 0, 0}; acc_im[x][y] = (kb_d4){0, 0, 0, 0}; }
+        const int K = n - k_hi;                              // stored rows j = k_hi .. n-1
+        const int nch = (K + KB_AB_KC - 1) / KB_AB_KC;
+        // staging: A: thread -> (row ar, k ak);  B: thread -> column bc, rows bk, bk+2, bk+4, bk+6
+        const int ar = t & 31, ak = t >> 5;
+        const int bc = t & 127, bk = t >> 7;
+        cd ga, gb[4];
+        auto fetch = [&](int ch) {
+            const int j = k_hi + ch * KB_AB_KC;
+            ga = (ar < M && j + ak < n) ? H[(a0 + kb0 + ar) + (size_t)(a0 + j + ak) * l] : czero();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = j + bk + 2 * q;
+                gb[q] = (jj < n) ? P[(size_t)jj * (2 * KB_AB_TILE) + bc] : czero();
+            }
+        };
+        auto stage = [&](int buf) {
+            L.sa[buf][0][ak][ar] = ga.x; L.sa[buf][1][ak][ar] = ga.y;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { L.sb[buf][0][bk + 2 * q][bc] = gb[q].x; L.sb[buf][1][bk + 2 * q][bc] = gb[q].y; }
+        };
+        fetch(0);
+        stage(0);
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            const int buf = ch & 1;
+            if (ch + 1 < nch) fetch(ch + 1);
+#pragma unroll
+            for (int ks = 0; ks < KB_AB_KC; ks += 4) {
+                double are[2], aim[2], bre[2], bim[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    are[x] = L.sa[buf][0][ks + lk][x * 16 + li];
+                    aim[x] = L.sa[buf][1][ks + lk][x * 16 + li];
+                    bre[x] = L.sb[buf][0][ks + lk][wave * 32 + x * 16 + li];
+                    bim[x] = L.sb[buf][1][ks + lk][wave * 32 + x * 16 + li];
+                }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        // D[row][col] += A[row][k] B[k][col]: MFMA A operand = H (row = li), B operand = panel (col = li)
+                        acc_re[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[rb], bre[cb], acc_re[rb][cb], 0, 0, 0);
+                        acc_re[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[rb], bim[cb], acc_re[rb][cb], 0, 0, 0);
+                        acc_im[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[rb], bim[cb], acc_im[rb][cb], 0, 0, 0);
+                        acc_im[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[rb], bre[cb], acc_im[rb][cb], 0, 0, 0);
+                    }
+            }
+            if (ch + 1 < nch) stage(buf ^ 1);
+            __syncthreads();
+        }
+        // D element of lane (li, lk), register g: row = rb*16 + lk + 4 g, column = wave*32 + cb*16 + li
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    L.bf[rb * 16 + lk + 4 * g][wave * 32 + cb * 16 + li] = mk(acc_re[rb][cb][g], acc_im[rb][cb][g]);
+        __syncthreads();
+        // -- the triangle: rows k = k_hi .. kb0, two wavefronts (each 32 roots: lanes 0-31 x, 32-63 y), no block barrier
+        if (wave < 2) {
+            const int c = wave * 64 + lane;                  // this lane's column
+            const int which = lane >> 5;                     // 0: x, 1: y
+            const int cx = wave * 64 + (lane & 31);          // the x column of the same root
+            const int root = wave * 32 + (lane & 31);
+            const cd z = L.z[root];
+            for (int r = M - 1; r >= 0; --r) {
+                const int k = kb0 + r;
+                const cd pk = (r == M - 1) ? L.prow[c] : L.bf[r + 1][c];      // p_k (own column)
+                cd s = L.bf[r][c];
+                for (int j = r; j < M - 1; ++j) cfma(s, L.ht[r][j], L.bf[j + 1][c]);      // H[k, k0+j] p_{k0+j}
+                s = s - z * pk;
+                if (which) s = s - ((r == M - 1) ? L.prow[cx] : L.bf[r + 1][cx]);
+                const cd res = (k >= 1) ? -(s * L.inv[r]) : s;
+                __builtin_amdgcn_wave_barrier();
+                L.bf[r][c] = res;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (kb0 == 0) break;                                 // bf[0] holds rho (x columns) and rho' (y columns)
+        // -- store the finished rows kb0-1 .. k_hi-1, rescale the columns if they have grown or shrunk a lot
+        if (t < 2 * KB_AB_TILE) {
+            const int c = t;
+            const cd top = L.bf[0][c];
+            L.prow[c] = top;
+        }
+        for (int e = t; e < M * 2 * KB_AB_TILE; e += 256) {
+            const int r = e >> 7, c = e & 127;
+            P[(size_t)(kb0 + r - 1) * (2 * KB_AB_TILE) + c] = L.bf[r][c];
+        }
+        if (t < KB_AB_TILE) {                                // scale decision per root from |x| of the newest row
+            const int cxx = ab_col(t, 0);
+            const cd v = L.bf[0][cxx];
+            const double mx = fmax(fabs(v.x), fabs(v.y));
+            int e = 0;
+            if (mx > 0.0 && mx == mx && mx < 1.79769313486231570815e308) (void)frexp(mx, &e);
+            L.part[0][t][0] = (e > 60 || e < -60) ? ldexp(1.0, -e) : 1.0;
+            if (e > 60 || e < -60) L.flags[1] = 1;
+        }
+        __syncthreads();
+        if (L.flags[1]) {
+            // all finished rows of the rescaled columns (kb0-1 .. n-1), both x and y
+            for (size_t e = t; e < (size_t)(n - (kb0 - 1)) * 2 * KB_AB_TILE; e += 256) {
+                const int c = (int)(e & 127);
+                const int root = (c >> 6) * 32 + (c & 31);
+                const double f = L.part[0][root][0];
+                if (f != 1.0) {
+                    cd* p = &P[(size_t)(kb0 - 1) * (2 * KB_AB_TILE) + e];
+                    *p = f * (*p);
+                }
+            }
+            if (t < 2 * KB_AB_TILE) {
+                const int root = (t >> 6) * 32 + (t & 31);
+                L.prow[t] = L.part[0][root][0] * L.prow[t];
+            }
+            __syncthreads();
+            if (t == 0) L.flags[1] = 0;
+            __threadfence_block();
+        }
+        __syncthreads();
+        k_hi = kb0 - 1;
+    }
+    // ---- the Aberth update of this tile's roots
+    if (t < nr) {
+        const int root = t;
+        if (!ws.conv[a0 + r0 + root] || iter == 0) {
+            const cd rho = L.bf[0][ab_col(root, 0)], rhop = L.bf[0][ab_col(root, 1)];
+            double dz;
+            const cd zn = ab_update(L.z[root], rho, rhop, L.S[root], &dz);
+            zout[r0 + root] = zn;
+            ws.lastc[a0 + r0 + root] = dz;
+            ws.conv[a0 + r0 + root] = ab_converged(dz, zn, hnorm) ? 1 : 0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ab_finish(const kb::KbItem* __restrict__ items, const int* __restrict__ perm, const kb::cd* arena,
+                                                    const double* __restrict__ varena, double* dcarena, kb::cd* mu_out, int* needqr) {
+    using namespace kb;
+    const int item = perm[blockIdx.x];
+    if (needqr[item]) return;
+    const KbItem it = items[item];
+    const DevCtx ctx = make_ctx(0);
+    const int l = it.l;
+    const AbWs ws = ab_item_ws(it, dcarena);
+    const cd* H = arena + it.off[KB_BUF_H];
+    const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
+    const int D = ab_depth(l);
+    const cd* z = ws.z[(D * KB_AB_BUDGET) & 1];
+    int bad = 0;
+    cd t1 = czero(), t2 = czero(), s1 = czero(), s2 = czero();
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = threadIdx.x; k < l; k += blockDim.x) {
+        const cd zk = z[k];
+        if (!ab_finite(zk) || !ab_acceptable(ws.lastc[k], zk, hnorm)) bad = 1;
+        const cd d = H[k + (size_t)k * l];
+        t1 = t1 + d; t2 = t2 + d * d;
+        if (k + 1 < l) t2 = t2 + 2.0 * (H[(k + 1) + (size_t)k * l] * H[k + (size_t)(k + 1) * l]);
+        s1 = s1 + zk; s2 = s2 + zk * zk;
+        a1 += cabs(zk); a2 += abs2(zk);
+    }
+    t1 = ctx.block_sum(t1); t2 = ctx.block_sum(t2); s1 = ctx.block_sum(s1); s2 = ctx.block_sum(s2);
+    a1 = ctx.block_sum(a1); a2 = ctx.block_sum(a2);
+    bad = ctx.block_max(bad);
+    if (!(cabs(s1 - t1) <= 1e-9 * (a1 + 1e-300)) || !(cabs(s2 - t2) <= 1e-9 * (a2 + 1e-300))) bad = 1;
+    if (bad) {
+        if (threadIdx.x == 0) needqr[item] = 1;
+        return;
+    }
+    cd* mu = mu_out + it.line_off;
+    for (int k = threadIdx.x; k < l; k += blockDim.x) mu[k] = z[k];
+}

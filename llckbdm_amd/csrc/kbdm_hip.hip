@@ -108,6 +108,8 @@ struct kbdm_ctx {
     int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
     int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
     int win_hqr2 = KB2_WIN_DEV;   // its LDS window (fixed: the device chase is compiled for it)
+    int eig_ab = 1;       // eigenvalues by divide-and-conquer Ehrlich-Aberth (kb_aberth.hpp), QR iteration as the fallback;
+                          // 0: QR iteration for every member (KBDM_EIG_AB)
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
     double ws_budget_gib = 96.0;
     // multi-GPU: RCCL communicator (one per context) and the device buffers of the packed gather
@@ -137,7 +139,8 @@ struct kbdm_plan {
     std::vector<int64_t> line_off, sv_off;
     int64_t total_lines = 0, total_sv = 0;
     size_t arena_elems = 0, varena_elems = 0, dc_elems = 0;
-    double* d_dc = nullptr;        // divide-and-conquer workspace (doubles)
+    double* d_dc = nullptr;        // divide-and-conquer workspace (doubles): SVD tree, then the Aberth panels
+    int* d_needqr = nullptr;       // per member: 1 = the Ehrlich-Aberth path declined, the QR iteration solves it
     int* d_iwork = nullptr;
     cd* d_signals = nullptr;
     KbItem* d_items = nullptr;
@@ -167,7 +170,7 @@ size_t item_arena_elems(int m, int l) {
     (void)l;
     // A, Q, P, R, H : m*m complex each; then, counted in complex units, the divide-and-conquer workspace (six real
     // m x m arrays)
-    return 5 * (size_t)m * m + (size_t)(dc_ws_doubles(m) + 1) / 2;
+    return 5 * (size_t)m * m + (size_t)(std::max(dc_ws_doubles(m), ab_ws_doubles(l > 0 ? l : m)) + 1) / 2;
 }
 
 int set_lds_attr() {
@@ -175,6 +178,8 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_setup), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_iter), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_leaf), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -235,7 +240,7 @@ int plan_build(kbdm_plan* pl, const int32_t* sig_idx, const int32_t* m, const in
             used = 0; vused = 0; dused = 0; acct = 0;
         }
         acct += need;
-        it.dc_off = (long long)dused; dused += (size_t)dc_ws_doubles(it.m);
+        it.dc_off = (long long)dused; dused += (size_t)std::max(dc_ws_doubles(it.m), ab_ws_doubles(it.l));
         pl->dc_elems = std::max(pl->dc_elems, dused);
         const size_t M = (size_t)it.m * it.m;
         size_t o = used;
@@ -304,6 +309,8 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS *
                                        team2_rec_bytes(pl->ctx->win_hqr2)));
     HIPCHK(hipMalloc(&pl->d_dc, sizeof(double) * std::max<size_t>(pl->dc_elems, 1)));
+    HIPCHK(hipMalloc(&pl->d_needqr, sizeof(int) * std::max(B, 1)));
+    HIPCHK(hipMemset(pl->d_needqr, 0, sizeof(int) * std::max(B, 1)));
     if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
     return KBDM_OK;
 }
@@ -517,10 +524,42 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             HIPCHK(hipMalloc(&prof, sizeof(MsStats) * pl->B));
             HIPCHK(hipMemsetAsync(prof, 0, sizeof(MsStats) * pl->B, st));
         }
+        // Fast path: divide-and-conquer Ehrlich-Aberth for every member (kb_aberth.hpp): leaves, then KB_AB_BUDGET
+        // iteration launches per level (a tile whose roots have settled only copies them through), the check; the QR
+        // iteration below then runs for the members the path declined only.  The conservative retry mode skips it.
+        const bool aberth = ctx->eig_ab && !(pl->mode & KBDM_MODE_SOLO_QR);
+        if (aberth) {
+            const int Dmax = ab_depth(ch.lmax);
+            std::vector<int> gx(Dmax, 0);                      // workgroups per member and step: tiles x nodes of its level
+            {
+                int last_l = -1;
+                for (int i = 0; i < ch.count; ++i) {
+                    const int l = pl->items[pl->perm[ch.first + i]].l;
+                    if (l == last_l) continue;
+                    last_l = l;
+                    const int D = ab_depth(l);
+                    for (int s2 = 0; s2 < D; ++s2) {
+                        const int depth = D - 1 - s2;
+                        const int Tl = (ab_level_nmax(l, depth) + KB_AB_TILE - 1) / KB_AB_TILE;
+                        gx[s2] = std::max(gx[s2], Tl << depth);
+                    }
+                }
+            }
+            const int sml = KB_RED_BYTES + (3 * KB_AB_LEAF * KB_AB_LEAF + 3 * KB_AB_LEAF) * (int)sizeof(cd) + 64;
+            hipLaunchKernelGGL(k_ab_leaf, dim3(1 << Dmax, ch.count), dim3(64), sml, st, pl->d_items, perm, pl->d_arena, pl->d_dc,
+                               pl->d_needqr, sml);
+            for (int s2 = 0; s2 < Dmax; ++s2)
+                for (int itn = 0; itn < KB_AB_BUDGET; ++itn)
+                    hipLaunchKernelGGL(k_ab_iter, dim3(gx[s2], ch.count), dim3(256), sizeof(AbLds), st, pl->d_items, perm, pl->d_arena,
+                                       pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn);
+            hipLaunchKernelGGL(k_ab_finish, dim3(ch.count), dim3(256), KB_RED_BYTES, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
+                               pl->d_dc, pl->d_mu, pl->d_needqr);
+        }
+        const int* needqr = aberth ? pl->d_needqr : nullptr;
         // Large members of the critical lane run as two-workgroup teams (k_hqr_team); the remaining
         // members of the chunk run solo on the side stream (after k_gen(Qh)), concurrently.
         int nteam = 0;
-        if (ctx->team_hqr && !(pl->mode & KBDM_MODE_SOLO_QR) && win > 0 && ln.stream2 != ln.stream &&
+        if (!aberth && ctx->team_hqr && !(pl->mode & KBDM_MODE_SOLO_QR) && win > 0 && ln.stream2 != ln.stream &&
             (ch.lane == 0 || ctx->team_hqr > 1)) {
             int nside = 0;                                   // lanes that may run teams share the budget of resident teams
             for (int i = 0; i < ctx->nlanes; ++i) nside += (ctx->lanes[i].stream2 != ctx->lanes[i].stream) ? 1 : 0;
@@ -532,7 +571,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                                pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, pl->d_team, pl->d_rings, prof);
         }
         if (ch.count > nteam) {
-            hipStream_t ss = nteam > 0 ? ln.stream2 : st;
+            hipStream_t ss = nteam > 0 ? ln.stream2 : st;     // (the fallback behind the Aberth path stays on the main stream)
             // a bounded number of workgroups takes the members from a queue (they are sorted by size,
             // largest first): the launch lasts as long as its largest member either way, and the CUs it
             // does not occupy go to the other lane's / the next ensemble's throughput-bound stages
@@ -550,10 +589,11 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                 }
                 nwg = (int)std::ceil(1.15 * work / (lmax * lmax));
                 if (nwg > 192) nwg = 0;
+                if (aberth) nwg = std::min(std::max(nwg, 1), 16);      // a handful of workgroups for the rare fallback
             }
             int* queue = (nwg > 0 && nsolo > nwg && cidx < KB_QUEUE_WORDS) ? pl->d_iwork + 4 * pl->B + cidx : nullptr;
             hipLaunchKernelGGL(k_hqr2, dim3(queue ? nwg : nsolo), dim3(512), sm, ss, pl->d_items, perm + nteam,
-                               pl->d_arena, pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, prof, nsolo, queue);
+                               pl->d_arena, pl->d_mu, pl->d_status, sm, ctx->nb_hqr2, win, prof, nsolo, queue, needqr);
             if (nteam > 0) HIPCHK(hipEventRecord(ln.ev_join, ln.stream2));   // the join now covers Qh and the solo members
         }
         if (do_prof) {   // diagnostic build path only: synchronous dump of the largest item's counters
@@ -702,6 +742,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->nt_invit = env_int("KBDM_NT_INVIT", c->nt_invit);
     c->blocked = env_int("KBDM_BLOCKED", c->blocked);
     c->gen_wy = env_int("KBDM_GEN_WY", c->gen_wy);
+    c->eig_ab = env_int("KBDM_EIG_AB", c->eig_ab);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
     c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
@@ -756,7 +797,7 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
     hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork);
-    hipFree(pl->d_team); hipFree(pl->d_rings); hipFree(pl->d_dc);
+    hipFree(pl->d_team); hipFree(pl->d_rings); hipFree(pl->d_dc); hipFree(pl->d_needqr);
     if (pl->h_signals) hipHostFree(pl->h_signals);
     if (pl->h_out) hipHostFree(pl->h_out);
     for (auto& ch : pl->chunks)
@@ -793,6 +834,7 @@ int kbdm_plan_execute(kbdm_plan* pl) {
     HIPCHK(hipMemsetAsync(pl->d_status, 0, sizeof(int) * pl->B, st));
     HIPCHK(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * pl->B + KB_QUEUE_WORDS), st));
     HIPCHK(hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * pl->B, st));
+    HIPCHK(hipMemsetAsync(pl->d_needqr, 0, sizeof(int) * pl->B, st));
     // groups one after the other (they share the arena); inside a group one chunk per lane, all
     // lanes concurrently: fork from the main stream, join back into it
     size_t ci = 0;
@@ -848,6 +890,16 @@ int kbdm_plan_stage_ms(kbdm_plan* pl, float* ms, int n) {
         }
     for (int s = 0; s < n && s < KBDM_NSTAGES; ++s) ms[s] = pl->stage_ms[s];
     return KBDM_OK;
+}
+
+int kbdm_plan_eig_fallbacks(kbdm_plan* pl) {
+    if (!pl || pl->B == 0) return 0;
+    std::vector<int> h(pl->B);
+    if (hipStreamSynchronize(pl->ctx->stream) != hipSuccess ||
+        hipMemcpy(h.data(), pl->d_needqr, sizeof(int) * pl->B, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int n = 0;
+    for (int v : h) n += v ? 1 : 0;
+    return n;
 }
 
 int kbdm_plan_lane0_members(const kbdm_plan* pl) {
@@ -1274,6 +1326,7 @@ int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, doub
         HIPTRY(hipMemsetAsync(pl->d_status, 0, sizeof(int) * B, st));
         HIPTRY(hipMemsetAsync(pl->d_iwork, 0, sizeof(int) * (4 * B + KB_QUEUE_WORDS), st));     // member-queue counters
         HIPTRY(hipMemsetAsync(pl->d_team, 0, sizeof(TeamCtl) * B, st));
+        HIPTRY(hipMemsetAsync(pl->d_needqr, 0, sizeof(int) * B, st));
         Chunk& ch = pl->chunks[0];
         hipLaunchKernelGGL(k_transpose_in, dim3(64, B), dim3(256), 0, st, pl->d_items, d_dense, pl->d_arena, KB_BUF_P, 1);
         hipLaunchKernelGGL(k_fill_ones, dim3(B), dim3(256), 0, st, pl->d_items, pl->d_varena);

@@ -693,9 +693,12 @@ __global__ void __launch_bounds__(1024) k_hess(const KbItem* __restrict__ items,
 // another CU (far strip units).  Team-major numbering: a team's two workgroups are dispatched together.  The host
 // launches at most as many teams as fit the chip at one workgroup per CU, so every workgroup of the launch is
 // resident; all waits are bounded (abort flag + status bit).
+#include "kbdm_ab_kernels.hpp"
+
+// needqr != nullptr: only the members flagged there are solved (the fallback behind the Ehrlich-Aberth path).
 __global__ void __launch_bounds__(512) k_hqr2(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                    cd* arena, cd* mu_out, int* status, int smem_bytes, int nbmax,
-                                                   int win_w, MsStats* prof, int count, int* queue) {
+                                                   int win_w, MsStats* prof, int count, int* queue, const int* needqr) {
     const DevCtx ctx = make_ctx(smem_bytes);
     __shared__ int info;
     __shared__ int next;
@@ -709,6 +712,11 @@ __global__ void __launch_bounds__(512) k_hqr2(const KbItem* __restrict__ items, 
         }
         if ((unsigned)idx >= (unsigned)count) break;
         const int item = perm[idx];
+        if (needqr && !needqr[item]) {
+            if (!queue) break;
+            __syncthreads();
+            continue;
+        }
         const KbItem it = items[item];
         cd* Hc = arena + it.off[KB_BUF_H];
         cd* mu = mu_out + it.line_off;

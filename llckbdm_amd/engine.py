@@ -183,6 +183,10 @@ class Plan:
         """Members (the largest ones) in lane 0, whose stage timers `stage_ms` reports."""
         return int(self.engine.lib.kbdm_plan_lane0_members(self.handle))
 
+    def eig_fallbacks(self):
+        """Members of the last run that the Ehrlich-Aberth eigenvalue path handed to the QR iteration."""
+        return int(self.engine.lib.kbdm_plan_eig_fallbacks(self.handle))
+
     def lines_device_ptr(self):
         return self.engine.lib.kbdm_plan_lines_device(self.handle)
 

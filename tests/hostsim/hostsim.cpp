@@ -17,6 +17,7 @@
 #include "kb_hqr2.hpp"
 #include "kb_svd.hpp"
 #include "kb_bdsdc.hpp"
+#include "kb_aberth.hpp"
 
 using namespace kb;
 typedef std::complex<double> zc;
@@ -51,6 +52,21 @@ static void hs_bidiag_blocked(HostCtx& ctx, int m, cd* A, double* d, double* e, 
             }
     }
     bidiag(ctx, m, A, m, d, e, tq, tp, UR, m, npan * KB_NB);
+}
+
+// Eigenvalues of a Hessenberg matrix by the Ehrlich-Aberth path (kb_aberth.hpp: host reference), leaves by the small
+// QR iteration; returns 0, or 1 if the member would fall back to the QR iteration.
+static int hs_aberth_path(HostCtx& ctx, int n, const cd* Hc, double hnorm, cd* mu, long long* iters) {
+    auto leaf = [&](const cd* H, int ld, int a, int nn, cd* z) -> int {
+        std::vector<cd> S((size_t)nn * nn);
+        for (int c = 0; c < nn; ++c)
+            for (int r = 0; r < nn; ++r) S[r + (size_t)c * nn] = (r <= c + 1) ? H[(a + r) + (size_t)(a + c) * ld] : czero();
+        int info = 0;
+        WaveCtx<HostCtx> wc{ctx, nullptr, 0};
+        hqr_eigvals(wc, nn, S.data(), nn, z, &info);
+        return info;
+    };
+    return ab_host_eig(Hc, n, n, hnorm, mu, leaf, iters);
 }
 
 extern "C" {
@@ -161,7 +177,10 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     }
     int info = 0, weak = 0;
     cd* mu = reinterpret_cast<cd*>(mu_out);
-    hqr2_eigvals(ctx, n, Hc.data(), n, mu, &info, KB2_NBMAX, KB2_WIN_DEV);   // what k_hqr2 runs
+    // the device's order: the Ehrlich-Aberth path, the QR iteration (what k_hqr2 runs) for a member it declines
+    const char* abz = getenv("HS_EIG_AB");
+    if ((abz && atoi(abz) == 0) || hs_aberth_path(ctx, n, Hc.data(), hnorm, mu, nullptr) != 0)
+        hqr2_eigvals(ctx, n, Hc.data(), n, mu, &info, KB2_NBMAX, KB2_WIN_DEV);
     invit<HostCtx, 4096>(ctx, n, W.data(), n, mu, hnorm, X.data(), n, 1, &weak);
     // P = Qh * X
     cd* P = reinterpret_cast<cd*>(P_out);
@@ -174,6 +193,27 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     return info | (weak ? 4 : 0);
 }
 
+
+// The divide-and-conquer Ehrlich-Aberth path on its own: W (n x n column-major, any matrix: reduced to Hessenberg form
+// first) -> mu; out[0] = 1 if the path declined (the caller would run the QR iteration), out[1] = root iterations.
+int hs_eig_aberth(const double* W_in, int n, double* mu_out, long long* out) {
+    std::vector<cd> W(n * n), Hc(n * n), th(n);
+    memcpy(W.data(), W_in, sizeof(cd) * n * n);
+    std::vector<char> arena;
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + 4096);
+    gehd2(ctx, n, W.data(), n, th.data());
+    hess_copy(ctx, n, W.data(), n, Hc.data(), n);
+    double hnorm = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double r = 0.0;
+        for (int j = 0; j < n; ++j) r += cabs(Hc[i + (size_t)j * n]);
+        hnorm = r > hnorm ? r : hnorm;
+    }
+    long long iters = 0;
+    const int declined = hs_aberth_path(ctx, n, Hc.data(), hnorm, reinterpret_cast<cd*>(mu_out), &iters);
+    out[0] = declined; out[1] = iters;
+    return 0;
+}
 
 // The Aberth / Hyman small eigenvalue solver on its own: T upper Hessenberg n x n (column-major), z out.
 // Returns the solver's verdict (1 = converged).

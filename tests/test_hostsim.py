@@ -256,3 +256,45 @@ def test_divide_and_conquer_on_kbdm_hankel_bidiagonals(hs):
         assert np.abs(s - s_ref).max() <= 1e-14 * m * s_ref[0]
         L, R = Q @ X, Pm @ Y
         assert np.abs(L * s @ R.conj().T - A).max() <= 1e-13 * s_ref[0]
+
+
+def test_divide_and_conquer_aberth_eigenvalues(hs):
+    """kb_aberth.hpp (host reference of the device's fast eigenvalue path): random matrices and reduced KBDM matrices
+    (noise-free, noisy, l < m, q > 0) - every eigenvalue of LAPACK exactly once, a few iterations per root and level;
+    a matrix that splits is declined (the caller runs the QR iteration)."""
+    import scipy.linalg as sla
+    from oracle import kbdm_oracle as O
+    hs.hs_eig_aberth.argtypes = [P, ctypes.c_int, P, P]
+    rng = np.random.default_rng(4)
+
+    def run(W):
+        n = W.shape[0]
+        Wf = np.asfortranarray(W, dtype=complex)
+        mu, out = np.zeros(n, complex), np.zeros(2, np.int64)
+        assert hs.hs_eig_aberth(Wf.ctypes.data_as(P), n, mu.ctypes.data_as(P), out.ctypes.data_as(P)) == 0
+        return mu, int(out[0]), int(out[1])
+
+    def reduced(sig, m, l=None, q=0.0):
+        U0, Up1, Up = O.compute_U_matrices(sig, m, 1)
+        L, s, Rh = sla.svd(Up1)
+        l = l or m
+        d = 1 / np.sqrt(s[:l] + (q * q / s[:l] if q else 0))
+        return (d[:, None] * (L[:, :l].conj().T @ Up @ Rh[:l].conj().T)) * d[None, :]
+
+    cases = [rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) for n in (5, 33, 70, 150)]
+    sig = O.make_noisy(O.brain_sim_signal(1024), 1e-3, 0)
+    cases += [reduced(sig, 150), reduced(O.brain_sim_signal(1024), 120), reduced(sig, 140, l=60), reduced(sig, 130, q=1e-3)]
+    for W in cases:
+        n = W.shape[0]
+        mu, declined, iters = run(W)
+        assert declined == 0
+        ref = np.linalg.eigvals(W)
+        d = np.abs(mu[:, None] - ref[None, :])
+        assert d.min(axis=1).max() < 1e-11 * max(1.0, np.abs(ref).max()) * n
+        assert len(set(d.argmin(axis=1))) == n
+        if n > 32:
+            assert iters < 14 * n * np.log2(n / 16)          # a handful of iterations per root and level
+    A = rng.standard_normal((80, 80)) + 0j
+    A = np.triu(A, -1)
+    A[40, 39] = 0.0                                            # an exact split
+    assert run(A)[1] == 1
