@@ -54,13 +54,13 @@ KB_HD int ab_level_nmax(int l, int depth) {              // largest node of a le
     return n;
 }
 
-// Per-member workspace (doubles): roots z[2][l] (complex), last correction |dz| (l), converged flags (l ints), the
-// panels of the recurrence: [rows][128] complex, l * ceil(l / 64) rows.
+// Per-member workspace (doubles): roots z[2][l] (complex) and settled flags conv[2][l] (ints) of alternate iterations,
+// last correction |dz| (l), the panels of the recurrence: [rows][128] complex, l * ceil(l / 64) rows.
 struct AbWs {
     int l;
     cd* z[2];
     double* lastc;
-    int* conv;
+    int* conv[2];
     cd* panel;
 };
 KB_HD long long ab_ws_doubles(int l) {
@@ -71,7 +71,8 @@ KB_HD AbWs ab_ws(double* base, int l) {
     w.z[0] = reinterpret_cast<cd*>(base);
     w.z[1] = w.z[0] + l;
     w.lastc = base + 4 * (size_t)l;
-    w.conv = reinterpret_cast<int*>(w.lastc + l);
+    w.conv[0] = reinterpret_cast<int*>(w.lastc + l);
+    w.conv[1] = w.conv[0] + l;
     w.panel = reinterpret_cast<cd*>(base + ((6 * (size_t)l + 16 + 1) & ~(size_t)1));
     return w;
 }
@@ -100,8 +101,13 @@ KB_HD cd ab_update(cd z, cd rho, cd rhop, cd S, double* dz) {
     *dz = cabs(corr);
     return z - corr;
 }
-KB_HD bool ab_converged(double dz, cd z, double hnorm) { return dz <= 4.0 * KB_ULP * fmax(cabs(z), 1e-6 * hnorm); }
-KB_HD bool ab_acceptable(double dz, cd z, double hnorm) { return dz <= 1e-10 * fmax(cabs(z), 1e-6 * hnorm); }
+// A root has settled when its correction falls below 1e-10 |z|: the iteration converges cubically, so the root it
+// leaves behind is accurate to (correction)^3 / (separation)^2 - far below working precision for any separation that
+// working precision resolves; waiting for a correction of a few ulp costs every root one more iteration and roots
+// whose evaluation noise exceeds an ulp the whole budget.  A root that has not settled when the budget ends is still
+// accepted if its last correction is below 1e-9 |z| (noise-limited, condition number ~1e6 and beyond).
+KB_HD bool ab_converged(double dz, cd z, double hnorm) { return dz <= 1e-10 * fmax(cabs(z), 1e-6 * hnorm); }
+KB_HD bool ab_acceptable(double dz, cd z, double hnorm) { return dz <= 1e-9 * fmax(cabs(z), 1e-6 * hnorm); }
 
 // A subdiagonal entry that small splits the matrix: Hyman's recurrence divides by it (the QR iteration deflates there)
 KB_HD bool ab_negligible_sub(cd hsub, cd hk, cd hk1) {

@@ -19,8 +19,9 @@
 // (kb_smem, make_ctx, kb_d4 come from kbdm_kernels.hpp, which includes this file after kb_hqr2.hpp)
 
 constexpr int KB_AB_KC = 8;                     // k per staged chunk of the block product
-constexpr int KB_AB_PA = 40;                    // LDS pitch (doubles) of the H chunk rows  (32 rows + pad)
-constexpr int KB_AB_PB = 136;                   // LDS pitch (doubles) of the panel chunk rows (128 columns + pad)
+constexpr int KB_AB_PA = 48;                    // LDS pitch (doubles) of the H chunk rows: 2 * pitch = 32 mod 64 banks, so the two k rows
+                                                // of a half-wavefront's ds_read_b64 fall on disjoint banks
+constexpr int KB_AB_PB = 144;                   // LDS pitch (doubles) of the panel chunk rows (128 columns; same bank rule)
 
 struct AbLds {                                  // dynamic LDS of k_ab_iter
     double sa[2][2][KB_AB_KC][KB_AB_PA];        // [buffer][re|im][k][row]       H chunk
@@ -32,6 +33,8 @@ struct AbLds {                                  // dynamic LDS of k_ab_iter
     kb::cd z[KB_AB_TILE];
     kb::cd S[KB_AB_TILE];
     double part[4][KB_AB_TILE][2];
+    int cnt[256];                               // unsettled roots per thread of the flag scan
+    int ridx[KB_AB_TILE];                       // node-local index of this tile's roots
     int flags[8];
 };
 
@@ -40,8 +43,19 @@ __device__ __forceinline__ kb::AbWs ab_item_ws(const kb::KbItem& it, double* dca
 // column of the panel that holds root r's x (which = 0) / derivative (which = 1): a wavefront owns 32 roots with both
 __device__ __forceinline__ int ab_col(int r, int which) { return (r >> 5) * 64 + which * 32 + (r & 31); }
 
+// Sub-node (start, size) at depth d of a leaf of n rows that holds position j (the same halving as ab_node)
+__device__ __forceinline__ void ab_subnode(int n, int d, int j, int& sa, int& sn) {
+    sa = 0; sn = n;
+    for (int b = 0; b < d; ++b) {
+        const int h = sn / 2;
+        if (j < sa + h) sn = h; else { sa += h; sn -= h; }
+    }
+}
+
+// One wavefront per (member, leaf of <= 32 rows): the same divide and conquer INSIDE the leaf, down to 1 x 1 / 2 x 2
+// blocks (closed form), with the whole recurrence in LDS: lane r < 32 carries x of root r, lane r + 32 its derivative.
 __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ items, const int* __restrict__ perm, kb::cd* arena,
-                                                 double* dcarena, int* needqr, int smem_bytes) {
+                                                 const double* __restrict__ varena, double* dcarena, int* needqr, int smem_bytes) {
     using namespace kb;
     const int item = perm[blockIdx.y];
     const KbItem it = items[item];
@@ -50,8 +64,9 @@ __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ i
     const DevCtx ctx = make_ctx(smem_bytes);
     const cd* H = arena + it.off[KB_BUF_H];
     const AbWs ws = ab_item_ws(it, dcarena);
+    const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
     const int t = threadIdx.x;
-    if (blockIdx.x == 0) {                      // the subdiagonal scan and the reset of the member's flags
+    if (blockIdx.x == 0) {                      // the subdiagonal scan
         int bad = 0;
         for (int k = 1 + t; k < l; k += 64)
             if (ab_negligible_sub(H[k + (size_t)(k - 1) * l], H[k + (size_t)k * l], H[(k - 1) + (size_t)(k - 1) * l])) bad = 1;
@@ -59,33 +74,100 @@ __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ i
         if (t == 0 && bad) atomicOr(&needqr[item], 1);
     }
     const AbNode nd = ab_node(l, D, blockIdx.x);
-    const int n = nd.n;
-    cd* S = reinterpret_cast<cd*>(ctx.scratch());
-    cd* sh = S + KB_AB_LEAF * KB_AB_LEAF;
-    cd* aws = sh + KB_AB_LEAF;
-    int* sinfo = reinterpret_cast<int*>(aws + 2 * KB_AB_LEAF * KB_AB_LEAF + 2 * KB_AB_LEAF);
-    for (int idx = t; idx < n * n; idx += 64) {
-        const int r = idx % n, c = idx / n;
-        S[r + c * n] = (r <= c + 1) ? H[(nd.a + r) + (size_t)(nd.a + c) * l] : czero();
+    const int n = nd.n, a = nd.a;
+    __shared__ cd Hl[KB_AB_LEAF][KB_AB_LEAF + 1];
+    __shared__ cd XY[2][KB_AB_LEAF][KB_AB_LEAF + 1];       // [x | y][row k][root]
+    __shared__ cd inv[KB_AB_LEAF], zl[KB_AB_LEAF], rr[2][KB_AB_LEAF];
+    for (int idx = t; idx < KB_AB_LEAF * KB_AB_LEAF; idx += 64) {
+        const int r = idx & 31, c = idx >> 5;
+        Hl[r][c] = (r < n && c < n && r <= c + 1) ? H[(a + r) + (size_t)(a + c) * l] : czero();
     }
-    if (t == 0) *sinfo = 0;
-    ctx.sync();
-    if (n == 1) { if (t == 0) sh[0] = S[0]; }
-    else if (n == 2) { if (t == 0) eig2x2(S[0], S[2], S[1], S[3], sh[0], sh[1]); }
-    else hqr2_shifts(ctx, n, S, sh, aws, sinfo, (MsStats*)nullptr);
-    ctx.sync();
-    for (int r = t; r < n; r += 64) {
-        ws.z[0][nd.a + r] = sh[r];
-        ws.conv[nd.a + r] = 1;
-        ws.lastc[nd.a + r] = 0.0;
+    __syncthreads();
+    if (t < KB_AB_LEAF) inv[t] = (t >= 1 && t < n) ? ab_recip(Hl[t][t - 1]) : czero();
+    const int root = t & 31, which = t >> 5;
+    // depth of the inner tree: halve until every block has at most two rows
+    int dl = 0;
+    for (int s2 = n; s2 > 2; s2 = s2 - s2 / 2) ++dl;
+    int sa, sn;
+    ab_subnode(n, dl, root < n ? root : 0, sa, sn);
+    if (which == 0 && root < n) {               // closed forms
+        cd z1 = Hl[sa][sa], z2 = z1;
+        if (sn == 2) eig2x2(Hl[sa][sa], Hl[sa][sa + 1], Hl[sa + 1][sa], Hl[sa + 1][sa + 1], z1, z2);
+        zl[root] = (root == sa) ? z1 : z2;
     }
-    if (t == 0 && *sinfo != 0) atomicOr(&needqr[item], 1);
+    __syncthreads();
+    int failed = 0;
+    for (int d = dl - 1; d >= 0; --d) {
+        ab_subnode(n, d, root < n ? root : 0, sa, sn);
+        const bool live = root < n;
+        cd z = live ? ab_perturb(zl[root], a + root, hnorm) : czero();
+        __syncthreads();
+        if (which == 0 && live) zl[root] = z;
+        __syncthreads();
+        bool settled = !live;
+        double lastdz = 0.0;
+        const int snmax = (n >> d) + 1;                       // (an upper bound of the node sizes of this depth)
+        for (int iter = 0; iter < 40; ++iter) {
+            if (__ballot(!settled) == 0ull) break;
+            // Hyman's recurrence of this lane's root in its node: rows sn-1 .. 0
+            if (live) XY[which][sn - 1][root] = which ? czero() : mk(1.0, 0.0);
+            cd rho = czero();
+            for (int k = snmax - 1; k >= 0; --k) {
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (live && k < sn) {
+                    cd s = czero(), s1 = czero();
+                    int j = k;
+                    for (; j + 1 < sn; j += 2) {
+                        cfma(s, Hl[sa + k][sa + j], XY[which][j][root]);
+                        cfma(s1, Hl[sa + k][sa + j + 1], XY[which][j + 1][root]);
+                    }
+                    if (j < sn) cfma(s, Hl[sa + k][sa + j], XY[which][j][root]);
+                    s = s + s1;
+                    s = s - z * XY[which][k][root];
+                    if (which) s = s - XY[0][k][root];
+                    if (k >= 1) XY[which][k - 1][root] = -(s * inv[sa + k]);
+                    else rho = s;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (live) rr[which][root] = rho;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            cd zn = z;
+            if (which == 0 && live && !settled) {
+                cd S = czero();
+                for (int j = sa; j < sa + sn; ++j)
+                    if (j != root) S = S + ab_recip(z - zl[j]);
+                double dz;
+                zn = ab_update(z, rr[0][root], rr[1][root], S, &dz);
+                lastdz = dz;
+                if (ab_converged(dz, zn, hnorm)) settled = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (which == 0 && live) zl[root] = zn;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            z = live ? zl[root] : czero();
+            // the derivative lane follows its root's state
+            const int st_x = __shfl(settled ? 1 : 0, root, 64);
+            if (which) settled = st_x != 0;
+        }
+        if (which == 0 && live && !ab_acceptable(lastdz, z, hnorm)) failed = 1;
+    }
+    failed = ctx.block_max(failed);
+    if (t < n) {
+        ws.z[0][a + t] = zl[t];
+        ws.conv[0][a + t] = 1;
+        ws.lastc[a + t] = 0.0;
+    }
+    if (t == 0 && failed) atomicOr(&needqr[item], 1);
 }
 
 // grid (tiles * nodes of the deepest level of this step, members); block 256; dynamic LDS sizeof(AbLds)
 __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ items, const int* __restrict__ perm,
                                                   const kb::cd* __restrict__ arena, const double* __restrict__ varena, double* dcarena,
-                                                  const int* __restrict__ needqr, int step, int iter) {
+                                                  const int* __restrict__ needqr, int step, int iter, int* abstat, int dbg) {
     using namespace kb;
     const int item = perm[blockIdx.y];
     if (needqr[item]) return;
@@ -98,42 +180,64 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     const AbNode nd = ab_node(l, depth, idx);
     const int n = nd.n, a0 = nd.a;
     if (tile * KB_AB_TILE >= n) return;
-    const int r0 = tile * KB_AB_TILE;                       // first root of this tile (local to the node)
-    const int nr = (n - r0 < KB_AB_TILE) ? n - r0 : KB_AB_TILE;
     AbLds& L = *reinterpret_cast<AbLds*>(kb_smem);
     const AbWs ws = ab_item_ws(it, dcarena);
     const int bin = (step * KB_AB_BUDGET + iter) & 1;
     const cd* zin = ws.z[bin] + a0;
     cd* zout = ws.z[bin ^ 1] + a0;
+    const int* cin = ws.conv[bin] + a0;
+    int* cout = ws.conv[bin ^ 1] + a0;
     const cd* H = arena + it.off[KB_BUF_H];
     const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
     const int t = threadIdx.x;
-    // ---- this tile's roots; the first iteration of a level separates the starting values and re-opens every root
-    if (t == 0) L.flags[0] = 0;
-    __syncthreads();
-    if (t < KB_AB_TILE) {
-        cd z = mk(0.0, 0.0);
-        int cv = 1;
-        if (t < nr) {
-            z = zin[r0 + t];
-            cv = ws.conv[a0 + r0 + t];
-            if (iter == 0) { z = ab_perturb(z, a0 + r0 + t, hnorm); cv = 0; }
-            if (!cv) L.flags[0] = 1;
+    // ---- the unsettled roots of the node, compacted: tile k takes the 64 k-th .. of them.  Every workgroup of the node
+    // scans the node's flags (of the previous iteration: double buffered, so all of them see the same set) and carries
+    // the settled roots through - identical values from every workgroup.  The first iteration of a level re-opens every
+    // root (the children's eigenvalues are only starting values) and separates coincident ones.
+    const int per = (n + 255) / 256;
+    const int j0 = t * per, j1 = (j0 + per < n) ? j0 + per : n;
+    {
+        int c = 0;
+        for (int j = j0; j < j1; ++j) {
+            if (iter != 0 && cin[j]) { zout[j] = zin[j]; cout[j] = 1; }
+            else ++c;
         }
-        L.z[t] = z;
-        L.flags[1 + 0] = 0;
-        if (t < nr && cv) zout[r0 + t] = z;                 // settled roots are carried through
+        L.cnt[t] = c;
+        if (t == 0) L.flags[1] = 0;
     }
     __syncthreads();
-    if (!L.flags[0]) return;                                // every root of the tile has settled
+    int rank = 0;
+    for (int u = 0; u < t; ++u) rank += L.cnt[u];
+    if (t == 255) L.flags[0] = rank + L.cnt[255];
+    for (int j = j0; j < j1; ++j)
+        if (iter == 0 || !cin[j]) {
+            const int q = rank - tile * KB_AB_TILE;
+            if (q >= 0 && q < KB_AB_TILE) L.ridx[q] = j;
+            ++rank;
+        }
+    __syncthreads();
+    const int nactive = L.flags[0];
+    const int nr = (nactive - tile * KB_AB_TILE < KB_AB_TILE) ? nactive - tile * KB_AB_TILE : KB_AB_TILE;
+    if (nr <= 0) return;                                    // this tile has nothing left to iterate
+    if (abstat && t == 0) atomicAdd(&abstat[step * KB_AB_BUDGET + iter], 1);
+    if (t < KB_AB_TILE) {
+        cd z = mk(0.0, 0.0);
+        if (t < nr) {
+            z = zin[L.ridx[t]];
+            if (iter == 0) z = ab_perturb(z, a0 + L.ridx[t], hnorm);
+        }
+        L.z[t] = z;
+    }
+    __syncthreads();
     // ---- repulsion sums S_i = sum_{j != i} 1 / (z_i - z_j) over the node (four threads per root)
     {
         const int i = t & 63, q = t >> 6;
         double sx = 0.0, sy = 0.0;
         if (i < nr) {
             const cd zi = L.z[i];
+            const int me = L.ridx[i];
             for (int j = q; j < n; j += 4) {
-                if (j == r0 + i) continue;
+                if (j == me) continue;
                 cd zj = zin[j];
                 if (iter == 0) zj = ab_perturb(zj, a0 + j, hnorm);
                 const cd d = zi - zj;
@@ -160,17 +264,20 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     }
     __syncthreads();
     int k_hi = n - 1;
+    int rho_slot = 0;
     while (k_hi >= 0) {
-        const int kb0 = (k_hi - (KB_AB_BLK - 1) > 0) ? k_hi - (KB_AB_BLK - 1) : 0;
-        const int M = k_hi - kb0 + 1;
+        // slot r of the block <-> row k = kb0s + r of the node, r = 0 .. 31; the topmost block has kb0s <= 0 and its
+        // slots below rmin are empty (k < 0)
+        const int kb0s = k_hi - (KB_AB_BLK - 1);
+        const int rmin = kb0s < 0 ? -kb0s : 0;
         // -- the block's triangle of H and the reciprocal subdiagonals
         for (int e = t; e < KB_AB_BLK * KB_AB_BLK; e += 256) {
             const int r = e & 31, j = e >> 5;
-            L.ht[r][j] = (r < M && j < M && j >= r - 1 && j >= 0) ? H[(a0 + kb0 + r) + (size_t)(a0 + kb0 + j) * l] : czero();
+            L.ht[r][j] = (r >= rmin && j >= rmin && j >= r - 1) ? H[(a0 + kb0s + r) + (size_t)(a0 + kb0s + j) * l] : czero();
         }
         if (t < KB_AB_BLK) {
-            const int k = kb0 + t;
-            L.inv[t] = (t < M && k >= 1) ? ab_recip(H[(a0 + k) + (size_t)(a0 + k - 1) * l]) : czero();
+            const int k = kb0s + t;
+            L.inv[t] = (k >= 1) ? ab_recip(H[(a0 + k) + (size_t)(a0 + k - 1) * l]) : czero();
         }
         // -- G[k] = sum_{j = k_hi}^{n-1} H[k, j] P[j, :]   (rows k of the block x 128 columns, MFMA)
         kb_d4 acc_re[2][2], acc_im[2][2];
@@ -186,7 +293,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         cd ga, gb[4];
         auto fetch = [&](int ch) {
             const int j = k_hi + ch * KB_AB_KC;
-            ga = (ar < M && j + ak < n) ? H[(a0 + kb0 + ar) + (size_t)(a0 + j + ak) * l] : czero();
+            ga = (ar >= rmin && j + ak < n) ? H[(a0 + kb0s + ar) + (size_t)(a0 + j + ak) * l] : czero();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int jj = j + bk + 2 * q;
@@ -201,7 +308,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         fetch(0);
         stage(0);
         __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
+        for (int ch = 0; ch < ((dbg & 1) ? 0 : nch); ++ch) {
             const int buf = ch & 1;
             if (ch + 1 < nch) fetch(ch + 1);
 #pragma unroll
@@ -237,38 +344,45 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
                 for (int g = 0; g < 4; ++g)
                     L.bf[rb * 16 + lk + 4 * g][wave * 32 + cb * 16 + li] = mk(acc_re[rb][cb][g], acc_im[rb][cb][g]);
         __syncthreads();
-        // -- the triangle: rows k = k_hi .. kb0, two wavefronts (each 32 roots: lanes 0-31 x, 32-63 y), no block barrier
-        if (wave < 2) {
+        // -- the triangle, two wavefronts (each 32 roots: lanes 0-31 x, lanes 32-63 the derivative): the running sums of
+        // all 32 rows of a column live in REGISTERS; as soon as p_{k-1} is known it is added into the rows above
+        // (right-looking), so a step is one dependent multiply plus independent updates, fully unrolled.
+        if (wave < 2 && !(dbg & 2)) {
             const int c = wave * 64 + lane;                  // this lane's column
-            const int which = lane >> 5;                     // 0: x, 1: y
-            const int cx = wave * 64 + (lane & 31);          // the x column of the same root
-            const int root = wave * 32 + (lane & 31);
-            const cd z = L.z[root];
-            for (int r = M - 1; r >= 0; --r) {
-                const int k = kb0 + r;
-                const cd pk = (r == M - 1) ? L.prow[c] : L.bf[r + 1][c];      // p_k (own column)
-                cd s = L.bf[r][c];
-                for (int j = r; j < M - 1; ++j) cfma(s, L.ht[r][j], L.bf[j + 1][c]);      // H[k, k0+j] p_{k0+j}
-                s = s - z * pk;
-                if (which) s = s - ((r == M - 1) ? L.prow[cx] : L.bf[r + 1][cx]);
-                const cd res = (k >= 1) ? -(s * L.inv[r]) : s;
-                __builtin_amdgcn_wave_barrier();
-                L.bf[r][c] = res;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
+            const bool isy = lane >= 32;
+            const cd z = L.z[wave * 32 + (lane & 31)];
+            cd rs[KB_AB_BLK];
+#pragma unroll
+            for (int r = 0; r < KB_AB_BLK; ++r) rs[r] = L.bf[r][c];
+            cd pk = L.prow[c];                               // p_k of the step's row (own column)
+#pragma unroll
+            for (int r = KB_AB_BLK - 1; r >= 0; --r) {
+                if (r >= rmin) {                             // (uniform)
+                    // the derivative lane needs x_k: the x lane of the same root is 32 lanes below
+                    const double xkx = __shfl(pk.x, lane & 31, 64), xky = __shfl(pk.y, lane & 31, 64);
+                    cd sv = rs[r] - z * pk;
+                    if (isy) sv = sv - mk(xkx, xky);
+                    const cd res = (kb0s + r >= 1) ? -(sv * L.inv[r]) : sv;
+                    rs[r] = res;
+                    pk = res;
+#pragma unroll
+                    for (int rp = 0; rp < r; ++rp) cfma(rs[rp], L.ht[rp][r - 1], res);       // H[k', k-1] p_{k-1}
+                }
             }
+#pragma unroll
+            for (int r = 0; r < KB_AB_BLK; ++r) L.bf[r][c] = rs[r];
         }
         __syncthreads();
-        if (kb0 == 0) break;                                 // bf[0] holds rho (x columns) and rho' (y columns)
-        // -- store the finished rows kb0-1 .. k_hi-1, rescale the columns if they have grown or shrunk a lot
+        if (kb0s <= 0) { rho_slot = rmin; break; }           // bf[rmin] holds rho (x columns) and rho' (y columns)
+        // -- store the finished rows kb0s-1 .. k_hi-1, rescale the columns if they have grown or shrunk a lot
         if (t < 2 * KB_AB_TILE) {
             const int c = t;
             const cd top = L.bf[0][c];
             L.prow[c] = top;
         }
-        for (int e = t; e < M * 2 * KB_AB_TILE; e += 256) {
+        for (int e = t; e < KB_AB_BLK * 2 * KB_AB_TILE; e += 256) {
             const int r = e >> 7, c = e & 127;
-            P[(size_t)(kb0 + r - 1) * (2 * KB_AB_TILE) + c] = L.bf[r][c];
+            P[(size_t)(kb0s + r - 1) * (2 * KB_AB_TILE) + c] = L.bf[r][c];
         }
         if (t < KB_AB_TILE) {                                // scale decision per root from |x| of the newest row
             const int cxx = ab_col(t, 0);
@@ -281,13 +395,13 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         }
         __syncthreads();
         if (L.flags[1]) {
-            // all finished rows of the rescaled columns (kb0-1 .. n-1), both x and y
-            for (size_t e = t; e < (size_t)(n - (kb0 - 1)) * 2 * KB_AB_TILE; e += 256) {
+            // all finished rows of the rescaled columns (kb0s-1 .. n-1), both x and y
+            for (size_t e = t; e < (size_t)(n - (kb0s - 1)) * 2 * KB_AB_TILE; e += 256) {
                 const int c = (int)(e & 127);
                 const int root = (c >> 6) * 32 + (c & 31);
                 const double f = L.part[0][root][0];
                 if (f != 1.0) {
-                    cd* p = &P[(size_t)(kb0 - 1) * (2 * KB_AB_TILE) + e];
+                    cd* p = &P[(size_t)(kb0s - 1) * (2 * KB_AB_TILE) + e];
                     *p = f * (*p);
                 }
             }
@@ -300,19 +414,17 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             __threadfence_block();
         }
         __syncthreads();
-        k_hi = kb0 - 1;
+        k_hi = kb0s - 1;
     }
     // ---- the Aberth update of this tile's roots
     if (t < nr) {
-        const int root = t;
-        if (!ws.conv[a0 + r0 + root] || iter == 0) {
-            const cd rho = L.bf[0][ab_col(root, 0)], rhop = L.bf[0][ab_col(root, 1)];
-            double dz;
-            const cd zn = ab_update(L.z[root], rho, rhop, L.S[root], &dz);
-            zout[r0 + root] = zn;
-            ws.lastc[a0 + r0 + root] = dz;
-            ws.conv[a0 + r0 + root] = ab_converged(dz, zn, hnorm) ? 1 : 0;
-        }
+        const int root = t, j = L.ridx[t];
+        const cd rho = L.bf[rho_slot][ab_col(root, 0)], rhop = L.bf[rho_slot][ab_col(root, 1)];
+        double dz;
+        const cd zn = ab_update(L.z[root], rho, rhop, L.S[root], &dz);
+        zout[j] = zn;
+        ws.lastc[a0 + j] = dz;
+        cout[j] = ab_converged(dz, zn, hnorm) ? 1 : 0;
     }
 }
 

@@ -140,6 +140,7 @@ struct kbdm_plan {
     int64_t total_lines = 0, total_sv = 0;
     size_t arena_elems = 0, varena_elems = 0, dc_elems = 0;
     double* d_dc = nullptr;        // divide-and-conquer workspace (doubles): SVD tree, then the Aberth panels
+    int* d_abstat = nullptr;       // working tiles per (step, iteration) of the Aberth path: 16 x KB_AB_BUDGET counters
     int* d_needqr = nullptr;       // per member: 1 = the Ehrlich-Aberth path declined, the QR iteration solves it
     int* d_iwork = nullptr;
     cd* d_signals = nullptr;
@@ -179,7 +180,6 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_setup), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_iter), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_leaf), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -309,6 +309,8 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS *
                                        team2_rec_bytes(pl->ctx->win_hqr2)));
     HIPCHK(hipMalloc(&pl->d_dc, sizeof(double) * std::max<size_t>(pl->dc_elems, 1)));
+    HIPCHK(hipMalloc(&pl->d_abstat, sizeof(int) * 16 * KB_AB_BUDGET));
+    HIPCHK(hipMemset(pl->d_abstat, 0, sizeof(int) * 16 * KB_AB_BUDGET));
     HIPCHK(hipMalloc(&pl->d_needqr, sizeof(int) * std::max(B, 1)));
     HIPCHK(hipMemset(pl->d_needqr, 0, sizeof(int) * std::max(B, 1)));
     if (pl->S > 0 && pl->N > 0) HIPCHK(hipMalloc(&pl->d_signals, sizeof(cd) * (size_t)pl->S * pl->N));
@@ -545,13 +547,13 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                     }
                 }
             }
-            const int sml = KB_RED_BYTES + (3 * KB_AB_LEAF * KB_AB_LEAF + 3 * KB_AB_LEAF) * (int)sizeof(cd) + 64;
-            hipLaunchKernelGGL(k_ab_leaf, dim3(1 << Dmax, ch.count), dim3(64), sml, st, pl->d_items, perm, pl->d_arena, pl->d_dc,
-                               pl->d_needqr, sml);
+            const int sml = KB_RED_BYTES;
+            hipLaunchKernelGGL(k_ab_leaf, dim3(1 << Dmax, ch.count), dim3(64), sml, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
+                               pl->d_dc, pl->d_needqr, sml);
             for (int s2 = 0; s2 < Dmax; ++s2)
                 for (int itn = 0; itn < KB_AB_BUDGET; ++itn)
                     hipLaunchKernelGGL(k_ab_iter, dim3(gx[s2], ch.count), dim3(256), sizeof(AbLds), st, pl->d_items, perm, pl->d_arena,
-                                       pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn);
+                                       pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn, pl->d_abstat, env_int("KBDM_AB_DBG", 0));
             hipLaunchKernelGGL(k_ab_finish, dim3(ch.count), dim3(256), KB_RED_BYTES, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
                                pl->d_dc, pl->d_mu, pl->d_needqr);
         }
@@ -797,7 +799,7 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
     hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork);
-    hipFree(pl->d_team); hipFree(pl->d_rings); hipFree(pl->d_dc); hipFree(pl->d_needqr);
+    hipFree(pl->d_team); hipFree(pl->d_rings); hipFree(pl->d_dc); hipFree(pl->d_needqr); hipFree(pl->d_abstat);
     if (pl->h_signals) hipHostFree(pl->h_signals);
     if (pl->h_out) hipHostFree(pl->h_out);
     for (auto& ch : pl->chunks)
@@ -900,6 +902,16 @@ int kbdm_plan_eig_fallbacks(kbdm_plan* pl) {
     int n = 0;
     for (int v : h) n += v ? 1 : 0;
     return n;
+}
+
+int kbdm_plan_ab_stats(kbdm_plan* pl, int32_t* out, int n) {
+    if (!pl || !out) return fail(KBDM_E_INVALID, "null argument");
+    std::vector<int> h(16 * KB_AB_BUDGET);
+    HIPCHK(hipStreamSynchronize(pl->ctx->stream));
+    HIPCHK(hipMemcpy(h.data(), pl->d_abstat, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < (int)h.size(); ++i) out[i] = h[i];
+    HIPCHK(hipMemset(pl->d_abstat, 0, sizeof(int) * h.size()));
+    return KBDM_OK;
 }
 
 int kbdm_plan_lane0_members(const kbdm_plan* pl) {

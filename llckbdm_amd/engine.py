@@ -187,6 +187,12 @@ class Plan:
         """Members of the last run that the Ehrlich-Aberth eigenvalue path handed to the QR iteration."""
         return int(self.engine.lib.kbdm_plan_eig_fallbacks(self.handle))
 
+    def ab_stats(self):
+        """Working root tiles per (step, iteration) of the Ehrlich-Aberth path since the last call: array (16, 24)."""
+        out = np.zeros(16 * 24, dtype=np.int32)
+        _lib.check(self.engine.lib.kbdm_plan_ab_stats(self.handle, _lib.ptr(out), out.size))
+        return out.reshape(16, 24)
+
     def lines_device_ptr(self):
         return self.engine.lib.kbdm_plan_lines_device(self.handle)
 
