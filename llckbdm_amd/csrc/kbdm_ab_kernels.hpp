@@ -355,19 +355,27 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
 #pragma unroll
             for (int r = 0; r < KB_AB_BLK; ++r) rs[r] = L.bf[r][c];
             cd pk = L.prow[c];                               // p_k of the step's row (own column)
+            // (slots below rmin - rows k < 0 of the topmost block - run through the same code on zeros: no branches, one
+            // basic block, so that the loads of the next steps' H columns are scheduled under the arithmetic of this one)
 #pragma unroll
             for (int r = KB_AB_BLK - 1; r >= 0; --r) {
-                if (r >= rmin) {                             // (uniform)
-                    // the derivative lane needs x_k: the x lane of the same root is 32 lanes below
-                    const double xkx = __shfl(pk.x, lane & 31, 64), xky = __shfl(pk.y, lane & 31, 64);
-                    cd sv = rs[r] - z * pk;
-                    if (isy) sv = sv - mk(xkx, xky);
-                    const cd res = (kb0s + r >= 1) ? -(sv * L.inv[r]) : sv;
-                    rs[r] = res;
-                    pk = res;
+                cd hc[KB_AB_BLK];
 #pragma unroll
-                    for (int rp = 0; rp < r; ++rp) cfma(rs[rp], L.ht[rp][r - 1], res);       // H[k', k-1] p_{k-1}
-                }
+                for (int rp = 0; rp < KB_AB_BLK - 1; ++rp)
+                    if (rp < r) hc[rp] = L.ht[rp][r > 0 ? r - 1 : 0];                      // H[k', k-1], rows above
+                const cd invr = L.inv[r];
+                // the derivative lane needs x_k: the x lane of the same root is 32 lanes below
+                const double xkx = __shfl(pk.x, lane & 31, 64), xky = __shfl(pk.y, lane & 31, 64);
+                cd sv = rs[r] - z * pk;
+                if (isy) sv = sv - mk(xkx, xky);
+                const cd mres = -(sv * invr);
+                const bool div = kb0s + r >= 1;
+                const cd res = mk(div ? mres.x : sv.x, div ? mres.y : sv.y);
+                rs[r] = res;
+                pk = res;
+#pragma unroll
+                for (int rp = 0; rp < KB_AB_BLK - 1; ++rp)
+                    if (rp < r) cfma(rs[rp], hc[rp], res);                                  // ... times p_{k-1}
             }
 #pragma unroll
             for (int r = 0; r < KB_AB_BLK; ++r) L.bf[r][c] = rs[r];
