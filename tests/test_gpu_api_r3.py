@@ -32,8 +32,9 @@ def _small_c2(seed, step=6):
 def test_flagged_members_are_retried_and_come_back_correct(eng, monkeypatch):
     """A status word that reports non-convergence on the first pass only (KBDM_DEBUG_FORCE_STATUS_ONCE: the test hook
     of kbdm_plan_collect flags every member of the next collected run, then disarms itself): through the drop-in
-    `sample_kbdm` the caller never sees it - the flagged members are solved again in the conservative mode (solo QR
-    iteration, no workgroup teams) and every line equals the undisturbed run's bit for bit."""
+    `sample_kbdm` the caller never sees it - the flagged members are solved again in the conservative mode (the QR
+    iteration in one workgroup per member instead of the Ehrlich-Aberth path) and every kept line agrees with the
+    undisturbed run's to 5e-8 (two eigenvalue algorithms: not the same bits), singular values bit for bit."""
     from llckbdm_amd.sampling import sample_kbdm
     sigs, _, ms = _small_c2(3)
     good_l, good_i = sample_kbdm(sigs[0], DWELL, ms.tolist(), p=1, l=None, q=0, engine=eng)
@@ -44,8 +45,15 @@ def test_flagged_members_are_retried_and_come_back_correct(eng, monkeypatch):
     monkeypatch.setenv("KBDM_DEBUG_FORCE_STATUS_ONCE", "2")
     got_l, got_i = sample_kbdm(sigs[0], DWELL, ms.tolist(), p=1, l=None, q=0, engine=eng)
     assert len(got_l) == len(good_l)
+    from tests.helpers import assert_lines_close, canonical
     for a, b, ia, ib in zip(got_l, good_l, got_i, good_i):
-        assert np.array_equal(a, b)
+        a, b = canonical(a), canonical(b)
+        strong = b[:, 0] > 1e-4
+        assert a.shape == b.shape
+        # (noise-fitted lines with A > 1e-4 move by up to 4e-8 between any two eigen-solvers: the spread BASELINE.md
+        # measures between LAPACK's own drivers; the genuine peaks agree to 1e-8 - tests/test_gpu_parity*.py)
+        assert_lines_close(a[strong], b[strong], rel=5e-8, phase_abs=5e-8, what="retried member")
+        assert_lines_close(a, b, rel=1e-6, phase_abs=1e-6, what="retried member (all kept lines)")
         assert np.array_equal(ia.singular_values, ib.singular_values)
 
 
