@@ -5,7 +5,7 @@ Metric (BASELINE.json): KBDM solves/sec over an m-range ensemble, N=2048 complex
 Default workload at every rank = BASELINE.json configs[1] ("C2"): 16-peak brain-sim signal + seeded
 sigma=1e-3 noise, members m = 100..400 step 2 (151 solves), l = m, p = 1, q = 0.
 One "step" = one whole ensemble through the pipeline (Hankel -> SVD -> reduced eig -> line lists), submitted
-through the package's public scheduler `Engine.submit` / `Pending.result` (three ensembles in flight on three
+through the package's public scheduler `Engine.submit` / `Pending.result` (four ensembles in flight on four
 contexts); `value` is measured with the signals already resident in HBM and the results landing in host memory,
 `host_to_host` with the upload inside the loop as well (the unit sampling.py:52-70 defines).
 With N > 1 ranks (one process per GPU; the launcher's RANK / LOCAL_RANK / WORLD_SIZE are read from the environment):
@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6],
                     help="ensembles (steps) in flight at once (Engine(in_flight=...): one context = three streams each; "
                          "every stream needs a hardware queue of its own: GPU_MAX_HW_QUEUES, 16 asked for here)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
@@ -273,6 +273,7 @@ def main():
             first = first or comms[c.value]
 
     stage_acc, nstage = {}, [0]
+    gather_t = [0.0, 0.0, 0]             # host seconds waiting for the plan / inside the gather call / calls
     timed = [False]
     gathered_ok = [True]
 
@@ -280,7 +281,12 @@ def main():
         """Retire a step: (multi-process) the one collective of the path, then the stage timers of its run."""
         if multi:
             comm = comms[h._slot.ctx.value]
-            comm.gather_plan(h.plan, sizes, root=0 if not args.sharded else 0)        # checked return code; waits
+            tg1 = time.perf_counter()
+            # enqueued behind the plan's run on the context's communication stream (checked return code); the context
+            # takes its next ensemble at once, the transfers are waited for before the clock stops
+            comm.gather_plan(h.plan, sizes, root=0, host=False)
+            gather_t[1] += time.perf_counter() - tg1
+            gather_t[2] += 1
         if timed[0]:
             for name, v in h.plan.stage_ms().items():      # HIP events of the critical lane (waits for the plan)
                 stage_acc[name] = stage_acc.get(name, 0.0) + v
@@ -288,6 +294,8 @@ def main():
 
     def sync_ranks():
         eng.drain()
+        for c in comms.values():
+            c.wait()                          # every gather of the timed region has landed
         if rdzv is not None:
             rdzv.barrier()
 
@@ -312,6 +320,7 @@ def main():
     ref = last.result(check=False)
     ok = int((ref.status == 0).sum())
     n0 = last.plan.lane0_members()        # members (the largest) whose stage timers `stage_ms` reports
+    nfb = last.plan.eig_fallbacks()       # members the Ehrlich-Aberth eigenvalue path handed to the QR iteration
     if multi:
         buf = comms[last._slot.ctx.value].gather_plan(last.plan, sizes, root=-1)       # to every rank, for the check
         off = int(sizes[:rank].sum())
@@ -365,6 +374,7 @@ def main():
                         others[name] = {"workload": WORKLOADS[name], "value": len(w[0][2]) * steps_o / to, "unit": "solves/s", "hankel_build": hk,
                                         "ms_per_step": 1e3 * to / steps_o, "steps": steps_o, "ensembles_in_flight": fl_o,
                                         "members": int(len(w[0][2])), "members_ok": int((chk.status == 0).sum()),
+                                        "eig_fallbacks": eng._slots[0].plans and max(pl.eig_fallbacks() for pl in eng._slots[0].plans.values()),
                                         "timed": "host -> host through Engine.submit"}
                     except Exception as e:       # informational lines: never lose the headline over them
                         others[name] = {"error": repr(e)}
@@ -386,7 +396,8 @@ def main():
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
         # the kernel behind the dominant stage timer (lane 0 runs the QR iteration as the team kernel)
-        kname = {"k_hqr": "k_hqr2_team", "k_svd_fac": "k_bidiag_panel<0>", "k_hess": "k_hess_panel",
+        kname = {"k_hqr": "k_ab_iter" if os.environ.get("KBDM_EIG_AB", "1") != "0" else "k_hqr2_team",
+                 "k_svd_fac": "k_bidiag_panel<0>", "k_hess": "k_hess_panel",
                  "k_gen(Q,P)": "k_wy_update", "k_dc_final": "k_dc_final", "k_invit": "k_invit_reg<8>"}.get(dom, dom)
         # HBM bytes per launch of that kernel: NOT measured by this run - taken from the newest committed PMC passes
         # (profiles/*_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command), if any
@@ -402,9 +413,12 @@ def main():
         except Exception:
             traffic = None
         roofline = {"kernel": kname, "stage_timer": dom,
-                    "bound": "mfma" if kname in ("k_trail_update", "k_hess_update") else "fp64_vector",
-                    "bound_note": "FP64 vector FMA, instruction-issue / latency bound (no MFMA in this kernel); "
-                                  "MI355X FP64 vector peak = FP64 matrix peak = 78.6 TFLOP/s",
+                    "bound": "mfma" if kname in ("k_trail_update", "k_hess_update", "k_ab_iter") else "fp64_vector",
+                    "bound_note": ("eigenvalue stage: Ehrlich-Aberth iterations (k_ab_iter: FP64-MFMA block products + a serial "
+                                   "32-row triangle per block), priced with the stage's algorithmic 65.33 l^3 flops per member "
+                                   "(SURVEY.md 8d) over the stage's HIP-event time" if kname == "k_ab_iter" else
+                                   "FP64 vector FMA, instruction-issue / latency bound; MI355X FP64 vector peak = FP64 matrix "
+                                   "peak = 78.6 TFLOP/s"),
                     "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_ms": stage_ms[dom], "algorithmic_flops_per_launch": fl[dom],
@@ -431,8 +445,10 @@ def main():
             "one_ensemble_at_a_time": serial,
             "host_to_host": host_incl,
             "other_configs": others or None,
+            "eig_fallbacks_last_step": nfb,
             "members_ok": min(ok_all), "members_ok_per_rank": ok_all,
             "gathered_blocks_verified": gathered_ok[0] if multi else None,
+            "gather_host_ms_per_call": 1e3 * gather_t[1] / max(1, gather_t[2]) if multi else None,
             "git_head": git_head(), "bench_sha256_16": file_sha(os.path.abspath(__file__)),
             "lib_sha256_16": file_sha(_lib.LIB_PATH),
         }

@@ -139,8 +139,13 @@ int64_t kbdm_packed_bytes(int64_t lines, int64_t sv, int64_t members);
 /* Packs this plan's results on the device and gathers the blocks of all `world` ranks (bytes[r] = block size of rank
  * r, blocks concatenated in rank order) with one grouped ncclSend/ncclRecv on the plan's stream: to every rank
  * (root < 0) or to `root` only.  host_out (sum of bytes, receiving ranks; may be null) gets a copy; the device copy
- * stays available through kbdm_gathered_device.  world == 1 needs no communicator. */
+ * stays available through kbdm_gathered_device (after kbdm_gather_wait).  world == 1 needs no communicator. */
 int kbdm_plan_gather(kbdm_plan* plan, int world, int rank, const int64_t* bytes, int root, void* host_out);
+/* The transfer runs on a communication stream of the context behind an event of the plan's stream: with host_out = null
+ * kbdm_plan_gather only ENQUEUES it and returns (the plan's context can take its next run at once; its pack buffer is
+ * reused only after the transfer); kbdm_gather_wait blocks until the context's last gather has landed.  With host_out
+ * the call itself waits. */
+int kbdm_gather_wait(kbdm_ctx* ctx);
 void* kbdm_gathered_device(kbdm_ctx* ctx);
 
 /* One-shot: plan + upload + execute + download. */

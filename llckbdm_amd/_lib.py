@@ -65,6 +65,7 @@ SYMBOLS = {
     "kbdm_packed_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "kbdm_plan_gather": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
     "kbdm_gathered_device": (_P, [_P]),
+    "kbdm_gather_wait": (c_int, [_P]),
     "kbdm_solve_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_double, c_double,
                                  _P, _P, _P, _P, _P]),
     "kbdm_hankel_batch": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),

@@ -116,6 +116,9 @@ struct kbdm_ctx {
     void* comm = nullptr;
     bool comm_owned = false;      // false: borrowed from another context of this process (kbdm_comm_attach)
     int comm_world = 0, comm_rank = 0;
+    hipStream_t comm_stream = nullptr;        // the gather runs here, behind an event of the plan's stream
+    hipEvent_t ev_packed = nullptr, ev_gathered = nullptr;
+    bool gather_pending = false;
     char* d_pack = nullptr;
     char* d_gather = nullptr;
     size_t pack_cap = 0, gather_cap = 0;
@@ -740,6 +743,8 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     }
     c->stream = c->lanes[0].stream;
     HIPCHK(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
     c->nt_fac = env_int("KBDM_NT_FAC", c->nt_fac);
     c->nt_invit = env_int("KBDM_NT_INVIT", c->nt_invit);
     c->blocked = env_int("KBDM_BLOCKED", c->blocked);
@@ -774,6 +779,9 @@ int kbdm_ctx_destroy(kbdm_ctx* ctx) {
         if (ln.ev_done) hipEventDestroy(ln.ev_done);
     }
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
+    if (ctx->comm_stream) { hipStreamSynchronize(ctx->comm_stream); hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->ev_packed) hipEventDestroy(ctx->ev_packed);
+    if (ctx->ev_gathered) hipEventDestroy(ctx->ev_gathered);
     if (ctx->comm) kbdm_comm_destroy(ctx);
     if (ctx->d_pack) hipFree(ctx->d_pack);
     if (ctx->d_gather) hipFree(ctx->d_gather);
@@ -1131,6 +1139,7 @@ int kbdm_comm_attach(kbdm_ctx* ctx, kbdm_ctx* owner) {
 int kbdm_comm_destroy(kbdm_ctx* ctx) {
     if (!ctx || !ctx->comm) return KBDM_OK;
     hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
     if (ctx->comm_owned) g_rccl.CommDestroy(ctx->comm);
     ctx->comm = nullptr;
     ctx->comm_owned = false;
@@ -1173,7 +1182,12 @@ int kbdm_plan_gather(kbdm_plan* pl, int world, int rank, const int64_t* bytes, i
         HIPCHK(hipMalloc(&ctx->d_gather, std::max<size_t>((size_t)total, 16)));
         ctx->gather_cap = std::max<size_t>((size_t)total, 16);
     }
-    // pack on the plan's stream (ordered after the run it belongs to)
+    // Pack on the plan's stream (ordered after the run it belongs to); the transfer itself runs on the context's
+    // communication stream behind an event, so that neither the host nor the plan's stream waits for the collective's
+    // kernel to find room on a busy GPU.  The pack buffer is reused only after the previous transfer has finished.
+    if (!ctx->comm_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    hipStream_t cs = ctx->comm_stream;
+    if (ctx->gather_pending) HIPCHK(hipStreamWaitEvent(st, ctx->ev_gathered, 0));
     char* d = ctx->d_pack;
     if (mine > 0) HIPCHK(hipMemsetAsync(d + (mine - 16), 0, 16, st));     // the padding bytes are defined
     if (pl->total_lines) HIPCHK(hipMemcpyAsync(d, pl->d_lines, 32 * pl->total_lines, hipMemcpyDeviceToDevice, st));
@@ -1183,25 +1197,36 @@ int kbdm_plan_gather(kbdm_plan* pl, int world, int rank, const int64_t* bytes, i
     if (pl->B) HIPCHK(hipMemcpyAsync(d, pl->d_status, 4 * (size_t)pl->B, hipMemcpyDeviceToDevice, st));
     d += 4 * (size_t)pl->B;
     if (pl->total_lines) HIPCHK(hipMemcpyAsync(d, pl->d_keep, pl->total_lines, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipEventRecord(ctx->ev_packed, st));
+    HIPCHK(hipStreamWaitEvent(cs, ctx->ev_packed, 0));
     const bool receive = root < 0 || root == rank;
     if (world == 1 && !ctx->comm) {
-        if (mine) HIPCHK(hipMemcpyAsync(ctx->d_gather, ctx->d_pack, mine, hipMemcpyDeviceToDevice, st));
+        if (mine) HIPCHK(hipMemcpyAsync(ctx->d_gather, ctx->d_pack, mine, hipMemcpyDeviceToDevice, cs));
     } else {
         // ONE grouped operation: every block travels once, straight between device buffers
         NCCLCHK(g_rccl.GroupStart());
         int err = 0;                              // the group is closed on every path out of here
         for (int r = 0; r < world && !err; ++r) {
             const bool to_r = root < 0 || r == root;
-            if (to_r && mine) err = g_rccl.Send(ctx->d_pack, (size_t)mine, kNcclUint8, r, ctx->comm, st);
+            if (to_r && mine) err = g_rccl.Send(ctx->d_pack, (size_t)mine, kNcclUint8, r, ctx->comm, cs);
             if (!err && receive && bytes[r])
-                err = g_rccl.Recv(ctx->d_gather + off[r], (size_t)bytes[r], kNcclUint8, r, ctx->comm, st);
+                err = g_rccl.Recv(ctx->d_gather + off[r], (size_t)bytes[r], kNcclUint8, r, ctx->comm, cs);
         }
         const int end = g_rccl.GroupEnd();
         NCCLCHK(err);
         NCCLCHK(end);
     }
-    if (host_out && receive && total) HIPCHK(hipMemcpyAsync(host_out, ctx->d_gather, total, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (host_out && receive && total) HIPCHK(hipMemcpyAsync(host_out, ctx->d_gather, total, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipEventRecord(ctx->ev_gathered, cs));
+    ctx->gather_pending = true;
+    if (host_out) HIPCHK(hipStreamSynchronize(cs));          // a host copy was asked for: the call completes it
+    return KBDM_OK;
+}
+
+int kbdm_gather_wait(kbdm_ctx* ctx) {
+    if (!ctx) return fail(KBDM_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->comm_stream) HIPCHK(hipStreamSynchronize(ctx->comm_stream));
     return KBDM_OK;
 }
 

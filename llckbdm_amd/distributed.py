@@ -112,13 +112,23 @@ class RcclComm:
                     plan.set_mode(0)
         return self.gather_plan(plan, sizes, root)
 
-    def gather_plan(self, plan, sizes, root=-1):
+    def gather_plan(self, plan, sizes, root=-1, host=True):
+        """The one collective of the path.  host=True: returns the concatenated host copy on receiving ranks (the call
+        waits); host=False: only enqueues the device-to-device transfer (`wait` completes it) and returns None."""
         sizes = np.ascontiguousarray(sizes, dtype=np.int64)
         recv = root < 0 or root == self.rank
-        out = np.empty(int(sizes.sum()), dtype=np.uint8) if recv else None
+        out = np.empty(int(sizes.sum()), dtype=np.uint8) if (recv and host) else None
         _lib.check(self.engine.lib.kbdm_plan_gather(plan.handle, self.world, self.rank, _lib.ptr(sizes), int(root),
                                                     _lib.ptr(out)))
+        if not host or (not recv):
+            if host:
+                self.wait()
+            return None
         return out
+
+    def wait(self):
+        """Block until this context's last gather has landed."""
+        _lib.check(self.engine.lib.kbdm_gather_wait(self.ctx))
 
     def close(self):
         if self.owns:

@@ -256,7 +256,7 @@ class Engine:
 
     # the second / third batch of a burst starts when the one before it has reached this stage: pipelines with the
     # same cycle keep the phase they start in, and started together they meet panels against panels
-    STAGGER_STAGE = {2: "k_hess", 3: "k_dc_sv"}
+    STAGGER_STAGE = {2: "k_hess", 3: "k_dc_sv", 4: "k_gen(Q,P)"}
 
     def __init__(self, device=None, in_flight=None):
         self.lib = _lib.load()
@@ -267,7 +267,7 @@ class Engine:
             raise _lib.KbdmHipError("no HIP device visible: llckbdm_amd needs an MI355X (gfx950); "
                                     "there is no CPU fallback")
         self.device = int(device) % n
-        self.in_flight = max(1, int(os.environ.get("KBDM_IN_FLIGHT", "3") if in_flight is None else in_flight))
+        self.in_flight = max(1, int(os.environ.get("KBDM_IN_FLIGHT", "4") if in_flight is None else in_flight))
         self._lock = threading.RLock()
         self._slots = [_Slot(self._new_ctx())]
         self.ctx = self._slots[0].ctx
