@@ -184,6 +184,8 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_setup), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_iter), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_tfac), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_apply), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -343,7 +345,8 @@ struct StageTimer {
 int smem_fac(int n, int nt) { return KB_RED_BYTES + bidiag_scratch_bytes(n, nt / 64, 64); }
 
 // Explicit unitary factors of a chunk: members with n >= KB_WY_MIN by blocked compact-WY accumulation on FP64 MFMA
-// (three launches per block of NB reflectors, last block first), the smaller ones by the per-column kernel k_gen
+// (the T factors of all blocks in one launch, then one launch per block of 64 reflectors, last block first), the smaller
+// ones by the per-column kernel k_gen
 // (smallest register-chunk count that covers the largest of them).
 int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream_t gst) {
     kbdm_ctx* ctx = pl->ctx;
@@ -351,21 +354,14 @@ int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream
     const int wy = ctx->gen_wy && nmax >= KB_WY_MIN;
     if (wy) {
         hipLaunchKernelGGL(k_wy_init, dim3(64, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode);
-        const int nblk = (nmax + KB_NB - 1) / KB_NB;
+        const int nblk = (nmax + KB_WYB - 1) / KB_WYB;
+        hipLaunchKernelGGL(k_wy_tfac, dim3(nblk, ch.count, nmat), dim3(256), KB_WY_LDS, gst, pl->d_items, perm, pl->d_arena, pl->d_varena,
+                           mode);
         for (int s = 0; s < nblk; ++s) {
-            // the block handled at step s of the LARGEST member starts at kb = (nblk - 1 - s) NB: its trailing size bounds the grids
-            const int span = std::min(nmax, nmax - (nblk - 1 - s) * KB_NB + 2 * KB_NB);    // (+ slack: a smaller member's block
-                                                                                        // grid may be a few rows taller)
-            const int tiles = (span + 63) / 64;
-            hipLaunchKernelGGL(k_wy_gram, dim3((span + KB_NB + 63) / 64, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm,
+            // a member's trailing matrix at step s has at most (s + 1) 64 + 2 rows (its last block is the partial one)
+            const int span = std::min(nmax, (s + 2) * KB_WYB);
+            hipLaunchKernelGGL(k_wy_apply, dim3((span + 63) / 64, ch.count, nmat), dim3(256), KB_WY_LDS, gst, pl->d_items, perm,
                                pl->d_arena, pl->d_varena, mode, s);
-            if (tiles > 8) {      // large members: T once per member and matrix, then the tile products
-                hipLaunchKernelGGL(k_wy_t, dim3(1, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s, 1);
-                hipLaunchKernelGGL(k_wy_t, dim3(tiles, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s, 2);
-            } else
-                hipLaunchKernelGGL(k_wy_t, dim3(tiles, ch.count, nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena, pl->d_varena, mode, s, 0);
-            hipLaunchKernelGGL(k_wy_update, dim3(tiles, tiles, ch.count * nmat), dim3(256), 0, gst, pl->d_items, perm, pl->d_arena,
-                               pl->d_varena, mode, s, nmat);
         }
     }
     // the per-column kernel for the members below KB_WY_MIN (all of them when the blocked path is off)

@@ -124,9 +124,9 @@ constexpr int KB_TU_PITCH = 80;   // doubles per k row in LDS
 // the unitary factors uses the panel height / 8 and NB / 8); STORE = false: C -= product, true: C = product.
 // KFAST: the operands are read k-fastest (thread t stages k = t & 7 of rows t >> 3 and (t >> 3) + 32): for products whose
 // operands are contiguous along k in memory (A^H B: both factors column-major with k = the row index).
+typedef double kb_tu_stage[2][2][KB_TU_KC][KB_TU_PITCH];       // [A|B][re|im][k][row]; a tile product needs two (double buffer)
 template <bool STORE, bool KFAST, class FA, class FB, class FC>
-__device__ __forceinline__ void mfma_tile_kx(FA Aop, FB Bop, FC Cptr, int NCH) {
-    __shared__ double s_op[2][2][2][KB_TU_KC][KB_TU_PITCH];   // [buffer][A|B][re|im][k][row]
+__device__ __forceinline__ void mfma_tile_ks(kb_tu_stage* s_op, FA Aop, FB Bop, FC Cptr, int NCH) {
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -206,6 +206,11 @@ __device__ __forceinline__ void mfma_tile_kx(FA Aop, FB Bop, FC Cptr, int NCH) {
             }
 }
 
+template <bool STORE, bool KFAST, class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_tile_kx(FA Aop, FB Bop, FC Cptr, int NCH) {
+    __shared__ kb_tu_stage s_op[2];
+    mfma_tile_ks<STORE, KFAST>(s_op, Aop, Bop, Cptr, NCH);
+}
 template <bool STORE, class FA, class FB, class FC>
 __device__ __forceinline__ void mfma_tile_k(FA Aop, FB Bop, FC Cptr, int NCH) {
     mfma_tile_kx<STORE, false>(Aop, Bop, Cptr, NCH);
@@ -304,20 +309,22 @@ __global__ void __launch_bounds__(256) k_gen(const KbItem* __restrict__ items, c
 // ------------------------------------------------------------------------------------
 // Explicit unitary factors by BLOCKED backward accumulation (the zungqr / zungbr organisation) on FP64 MFMA, for
 // members with n >= KB_WY_MIN (smaller ones keep the per-column kernel k_gen).  Q = H_0 H_1 ... H_{nref-1} is built
-// from the last block of NB reflectors to the first: with the block reflector  H_kb .. H_kb+NB-1 = I - V T V^H
-// (compact WY, T upper triangular NB x NB),  Out[p0:, p0:] <- (I - V T V^H) Out[p0:, p0:],  p0 = kb + shift, in three
-// launches per block for ALL members and both matrices:
-//   k_wy_gram   Zt = (V^H C)^T and Gt = (V^H V)^T as ONE tall product against V (MFMA tiles, k = panel height): every
-//               reflector panel is read once per 64 columns instead of once per column;
-//   k_wy_t      T from Gt and tau (zlarft), then Yc = conj(T Z)^T (NB x NB per column: vector code, one workgroup);
-//   k_wy_update C -= V Y as a rank-NB MFMA update.
+// from the last block of KB_WYB = 64 reflectors to the first: with the block reflector  H_kb .. H_kb+63 = I - V T V^H
+// (compact WY, T upper triangular),  Out[p0:, p0:] <- (I - V T V^H) Out[p0:, p0:],  p0 = kb + shift.
+//   k_wy_tfac   ONE launch for all blocks, members and matrices: G = V^H V of the block as an MFMA tile (k = panel
+//               height), then T from G and tau (zlarft, forward / columnwise) in LDS; T to the workspace;
+//   k_wy_apply  ONE launch per block: a workgroup owns 64 columns of the trailing matrix C = Out[p0:, p0:]:
+//               Z = V^H C (MFMA tile, k = panel height), Y = T Z (64 x 64 x 64), both kept in LDS, then
+//               C -= V Y row tile by row tile (rank-64 MFMA updates).  Every column tile is independent of the others,
+//               so a block costs one launch and the trailing matrix is read twice (the second time out of the L2).
 // The result is the same product of reflectors as k_gen's (rounding differs); flops 32/3 n^3 (Q, P) + 16/3 l^3 (Qh).
+constexpr int KB_WYB = 64;
 struct WyGeom {
     int n, nref, shift;
     const cd* V;          // reflector k: column k, rows > k + shift (1 at row k + shift, 0 above)
     const cd* tau;
     cd* Out;              // n x n
-    cd* ws;               // workspace of this matrix: Zt (n x NB), Yc (n x NB), Gt (NB x NB), T (NB x NB)
+    cd* Tws;              // workspace of this matrix: T of every block (64 x 64 each, T[j][k] at j * 64 + k)
 };
 __device__ __forceinline__ bool wy_geom(const KbItem& it, cd* arena, double* varena, int mode, int z, WyGeom& g) {
     double* dv = varena + it.voff;
@@ -332,7 +339,8 @@ __device__ __forceinline__ bool wy_geom(const KbItem& it, cd* arena, double* var
         g.V = arena + it.off[KB_BUF_P]; g.tau = reinterpret_cast<const cd*>(dv + KB_V_TAUQ * it.vstride); g.Out = arena + it.off[KB_BUF_Q];
         wsbase = arena + it.off[KB_BUF_A];            // L is dead after k_gemm<2>, B is written by k_gemm<4>
     }
-    g.ws = wsbase + (size_t)z * (2 * KB_NB * (size_t)g.n + 2 * KB_NB * KB_NB);
+    // 2 ceil(n / 64) 4096 <= n^2 elements for every n >= KB_WY_MIN = 192
+    g.Tws = wsbase + (size_t)z * ((g.n + KB_WYB - 1) / KB_WYB) * (KB_WYB * KB_WYB);
     return g.n >= KB_WY_MIN;
 }
 __device__ __forceinline__ cd wy_v(const WyGeom& g, int r, int k) {          // element (r, k) of the reflector matrix
@@ -341,10 +349,11 @@ __device__ __forceinline__ cd wy_v(const WyGeom& g, int r, int k) {          // 
     return r > p ? g.V[r + (size_t)k * g.n] : (r == p ? mk(1.0, 0.0) : czero());
 }
 // block handled at step s (s = 0: the last block); false if this member has fewer blocks
-__device__ __forceinline__ bool wy_block(const WyGeom& g, int step, int& kb, int& p0) {
-    const int nblk = (g.nref + KB_NB - 1) / KB_NB;
+__device__ __forceinline__ bool wy_block(const WyGeom& g, int step, int& blk, int& kb, int& p0) {
+    const int nblk = (g.nref + KB_WYB - 1) / KB_WYB;
     if (step >= nblk) return false;
-    kb = (nblk - 1 - step) * KB_NB;
+    blk = nblk - 1 - step;
+    kb = blk * KB_WYB;
     p0 = kb + g.shift;
     return true;
 }
@@ -361,109 +370,93 @@ __global__ void __launch_bounds__(256) k_wy_init(const KbItem* __restrict__ item
     }
 }
 
-__global__ void __launch_bounds__(256) k_wy_gram(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
-                                                  double* varena, int mode, int step) {
+constexpr int KB_WY_LDS = (int)(2 * sizeof(kb_tu_stage) + KB_WYB * (KB_WYB + 1) * sizeof(cd) + KB_WYB * sizeof(cd));
+
+__global__ void __launch_bounds__(256) k_wy_tfac(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
+                                                  double* varena, int mode) {
     const KbItem it = items[perm[blockIdx.y]];
     WyGeom g;
     if (!wy_geom(it, arena, varena, mode, blockIdx.z, g)) return;
-    int kb, p0;
-    if (!wy_block(g, step, kb, p0)) return;
-    const int nrows = g.n - p0, ncols = g.n - p0;
-    const int c0 = blockIdx.x * 64;
-    if (c0 >= ncols + KB_NB) return;
-    cd* Zt = g.ws;
-    cd* Gt = g.ws + 2 * KB_NB * (size_t)g.n;
-    // both operands are contiguous along the contraction index (the rows of Out and of V): k-fastest staging
-    mfma_tile_kx<true, true>(
-        [&](int i, int kk) -> cd {                 // rows of the product: columns of C, then the NB columns of V itself
-            const int c = c0 + i;
-            if (kk >= nrows) return czero();
-            if (c < ncols) return g.Out[(p0 + kk) + (size_t)(p0 + c) * g.n];
-            return (c < ncols + KB_NB) ? wy_v(g, p0 + kk, kb + (c - ncols)) : czero();
-        },
-        [&](int j, int kk) -> cd { return (j < KB_NB && kk < nrows) ? wy_v(g, p0 + kk, kb + j) : czero(); },
-        [&](int i, int j) -> cd* {
-            const int c = c0 + i;
-            if (j >= KB_NB) return nullptr;
-            if (c < ncols) return &Zt[c + (size_t)j * g.n];
-            return (c < ncols + KB_NB) ? &Gt[(c - ncols) + j * KB_NB] : nullptr;
-        },
+    const int nblk = (g.nref + KB_WYB - 1) / KB_WYB;
+    const int blk = blockIdx.x;
+    if (blk >= nblk) return;
+    const int kb = blk * KB_WYB, p0 = kb + g.shift, nrows = g.n - p0;
+    extern __shared__ __align__(16) unsigned char wy_smem[];
+    kb_tu_stage* s_op = reinterpret_cast<kb_tu_stage*>(wy_smem);
+    cd (*G)[KB_WYB + 1] = reinterpret_cast<cd (*)[KB_WYB + 1]>(wy_smem + 2 * sizeof(kb_tu_stage));
+    cd* col = reinterpret_cast<cd*>(wy_smem + 2 * sizeof(kb_tu_stage) + KB_WYB * (KB_WYB + 1) * sizeof(cd));
+    // G[i][l] = sum_r V[r][i] conj(V[r][l]) = (V^H v_i)[l]; both operands contiguous along the contraction index
+    mfma_tile_ks<true, true>(
+        s_op,
+        [&](int i, int kk) -> cd { return kk < nrows ? wy_v(g, p0 + kk, kb + i) : czero(); },
+        [&](int j, int kk) -> cd { return kk < nrows ? wy_v(g, p0 + kk, kb + j) : czero(); },
+        [&](int i, int j) -> cd* { return &G[i][j]; },
         (nrows + KB_TU_KC - 1) / KB_TU_KC);
+    __syncthreads();
+    // zlarft, forward / columnwise:  T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i.  In place: column i of T
+    // replaces row i of G (G[i][t] <- T[t][i], t <= i); a step reads only row i of G and finished columns of T.
+    const int t = threadIdx.x;
+    for (int i = 0; i < KB_WYB; ++i) {
+        const cd ti = (kb + i < g.nref) ? g.tau[kb + i] : czero();
+        if (t < i) col[t] = -(ti * G[i][t]);
+        __syncthreads();
+        if (t < i) {
+            cd acc = czero();
+            for (int l = t; l < i; ++l) cfma(acc, G[l][t], col[l]);
+            G[i][t] = acc;
+        }
+        if (t == i) G[i][i] = ti;
+        __syncthreads();
+    }
+    cd* Tg = g.Tws + (size_t)blk * (KB_WYB * KB_WYB);
+    for (int e = t; e < KB_WYB * KB_WYB; e += blockDim.x) {
+        const int j = e / KB_WYB, k = e % KB_WYB;
+        Tg[e] = (k >= j) ? G[k][j] : czero();
+    }
 }
 
-__global__ void __launch_bounds__(256) k_wy_t(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
-                                               double* varena, int mode, int step, int part) {
-    // part 0: every column tile forms T itself and multiplies (members of a few tiles: cheaper than another launch);
-    // part 1: one workgroup per member and matrix forms T and leaves it in the workspace; part 2: the tiles multiply with
-    // that T (large members: 19 tiles at n = 1200 would each repeat the 32 serial steps of zlarft - 2 of the 10.8 s of a
-    // C4 step before the split).  Same arithmetic either way.
+__global__ void __launch_bounds__(256) k_wy_apply(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
+                                                   double* varena, int mode, int step) {
     const KbItem it = items[perm[blockIdx.y]];
     WyGeom g;
     if (!wy_geom(it, arena, varena, mode, blockIdx.z, g)) return;
-    int kb, p0;
-    if (!wy_block(g, step, kb, p0)) return;
-    const int ncols = g.n - p0;
+    int blk, kb, p0;
+    if (!wy_block(g, step, blk, kb, p0)) return;
+    const int nrows = g.n - p0, ncols = g.n - p0;
     const int c0 = blockIdx.x * 64;
     if (c0 >= ncols) return;
-    const cd* Zt = g.ws;
-    cd* Yc = g.ws + KB_NB * (size_t)g.n;
-    const cd* Gt = g.ws + 2 * KB_NB * (size_t)g.n;
-    cd* Tg = g.ws + 2 * KB_NB * (size_t)g.n + KB_NB * KB_NB;
-    __shared__ cd T[KB_NB][KB_NB + 1];
-    __shared__ cd col[KB_NB];
-    const int t = threadIdx.x;
-    if (part == 2) {
-        for (int e = t; e < KB_NB * KB_NB; e += blockDim.x) T[e / KB_NB][e % KB_NB] = Tg[e];
-        __syncthreads();
-    } else {
-        for (int e = t; e < KB_NB * (KB_NB + 1); e += blockDim.x) (&T[0][0])[e] = czero();
-        __syncthreads();
-        // zlarft, forward / columnwise: T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i;  G(l, i) = Gt[i + l NB].
-        for (int i = 0; i < KB_NB; ++i) {
-            const cd ti = (kb + i < g.nref) ? g.tau[kb + i] : czero();
-            if (t < i) col[t] = -(ti * Gt[i + t * KB_NB]);
-            __syncthreads();
-            if (t < i) {
-                cd acc = czero();
-                for (int l = t; l < i; ++l) cfma(acc, T[t][l], col[l]);
-                T[t][i] = acc;
-            }
-            if (t == i) T[i][i] = ti;
-            __syncthreads();
-        }
-        if (part == 1) {
-            for (int e = t; e < KB_NB * KB_NB; e += blockDim.x) Tg[e] = T[e / KB_NB][e % KB_NB];
-            return;
-        }
-    }
-    // Yc[c, j] = conj( sum_k T[j, k] Z[k, c] ) = sum_k conj(Zt[c, k]) conj(T[j, k]):  one 64 x 32 MFMA tile, k = NB
-    mfma_tile_k<true>(
-        [&](int i, int k) -> cd { return (k < KB_NB && c0 + i < ncols) ? conj(Zt[(c0 + i) + (size_t)k * g.n]) : czero(); },
-        [&](int j, int k) -> cd { return (j < KB_NB && k < KB_NB) ? T[j][k] : czero(); },
-        [&](int i, int j) -> cd* { return (j < KB_NB && c0 + i < ncols) ? &Yc[(c0 + i) + (size_t)j * g.n] : nullptr; },
-        KB_NB / KB_TU_KC);
-}
-
-__global__ void __launch_bounds__(256) k_wy_update(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
-                                                    double* varena, int mode, int step, int nmat) {
-    const int z = blockIdx.z % nmat;
-    const KbItem it = items[perm[blockIdx.z / nmat]];
-    WyGeom g;
-    if (!wy_geom(it, arena, varena, mode, z, g)) return;
-    int kb, p0;
-    if (!wy_block(g, step, kb, p0)) return;
-    const int nrows = g.n - p0, ncols = g.n - p0;
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    if (r0 >= nrows || c0 >= ncols) return;
-    const cd* Yc = g.ws + KB_NB * (size_t)g.n;
-    mfma_tile_k<false>(
-        [&](int i, int j) -> cd { return (j < KB_NB) ? wy_v(g, p0 + r0 + i, kb + j) : czero(); },
-        [&](int i, int j) -> cd { return (j < KB_NB && c0 + i < ncols) ? Yc[(c0 + i) + (size_t)j * g.n] : czero(); },
-        [&](int i, int jx) -> cd* {
-            const int r = r0 + i, c = c0 + jx;
-            return (r < nrows && c < ncols) ? &g.Out[(p0 + r) + (size_t)(p0 + c) * g.n] : nullptr;
-        },
-        KB_NB / KB_TU_KC);
+    extern __shared__ __align__(16) unsigned char wy_smem[];
+    kb_tu_stage* s_op = reinterpret_cast<kb_tu_stage*>(wy_smem);
+    cd (*Zs)[KB_WYB + 1] = reinterpret_cast<cd (*)[KB_WYB + 1]>(wy_smem + 2 * sizeof(kb_tu_stage));     // [column][reflector]
+    const cd* Tg = g.Tws + (size_t)blk * (KB_WYB * KB_WYB);
+    // Zs[c][j] = sum_r C[r][c] conj(V[r][j]) = (V^H C)[j][c]
+    mfma_tile_ks<true, true>(
+        s_op,
+        [&](int i, int kk) -> cd { return (kk < nrows && c0 + i < ncols) ? g.Out[(p0 + kk) + (size_t)(p0 + c0 + i) * g.n] : czero(); },
+        [&](int j, int kk) -> cd { return kk < nrows ? wy_v(g, p0 + kk, kb + j) : czero(); },
+        [&](int i, int j) -> cd* { return &Zs[i][j]; },
+        (nrows + KB_TU_KC - 1) / KB_TU_KC);
+    __syncthreads();
+    // Yc[c][j] = conj( sum_k T[j][k] Z[k][c] ) = sum_k conj(Zs[c][k]) conj(T[j][k]); written over Zs (the product's operand
+    // reads end at the barrier that closes its last chunk)
+    mfma_tile_ks<true, false>(
+        s_op,
+        [&](int i, int k) -> cd { return conj(Zs[i][k]); },
+        [&](int j, int k) -> cd { return Tg[j * KB_WYB + k]; },
+        [&](int i, int j) -> cd* { return &Zs[i][j]; },
+        KB_WYB / KB_TU_KC);
+    __syncthreads();
+    // C[r][c] -= sum_j V[r][j] Y[j][c],  Y[j][c] = conj(Yc[c][j])
+    for (int r0 = 0; r0 < nrows; r0 += 64)
+        mfma_tile_ks<false, false>(
+            s_op,
+            [&](int i, int j) -> cd { return wy_v(g, p0 + r0 + i, kb + j); },
+            [&](int i, int j) -> cd { return Zs[i][j]; },
+            [&](int i, int jx) -> cd* {
+                const int r = r0 + i, c = c0 + jx;
+                return (r < nrows && c < ncols) ? &g.Out[(p0 + r) + (size_t)(p0 + c) * g.n] : nullptr;
+            },
+            KB_WYB / KB_TU_KC);
 }
 
 #include "kbdm_dc_kernels.hpp"
