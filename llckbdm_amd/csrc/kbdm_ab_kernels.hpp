@@ -38,6 +38,25 @@ struct AbLds {                                  // dynamic LDS of k_ab_iter
     int flags[8];
 };
 
+// every lane gets the value of lane (lane & 31)
+__device__ __forceinline__ double ab_lower_half(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+// LDS access through a 32-bit LDS address + byte offset (see the triangle of k_ab_iter)
+typedef double ab_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) ab_d2 ab_lds_d2;
+__device__ __forceinline__ unsigned ab_lds_addr(const void* p) { return (unsigned)(size_t)p; }     // flat -> LDS: the low 32 bits
+__device__ __forceinline__ kb::cd ab_lds_ld(unsigned base, int off) {
+    const ab_d2 v = *reinterpret_cast<const ab_lds_d2*>((size_t)(base + (unsigned)off));
+    return kb::mk(v.x, v.y);
+}
+__device__ __forceinline__ void ab_lds_st(unsigned base, int off, kb::cd v) {
+    *reinterpret_cast<ab_lds_d2*>((size_t)(base + (unsigned)off)) = (ab_d2){v.x, v.y};
+}
+
 __device__ __forceinline__ kb::AbWs ab_item_ws(const kb::KbItem& it, double* dcarena) { return kb::ab_ws(dcarena + it.dc_off, it.l); }
 
 // column of the panel that holds root r's x (which = 0) / derivative (which = 1): a wavefront owns 32 roots with both
@@ -277,7 +296,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         }
         if (t < KB_AB_BLK) {
             const int k = kb0s + t;
-            L.inv[t] = (k >= 1) ? ab_recip(H[(a0 + k) + (size_t)(a0 + k - 1) * l]) : czero();
+            L.inv[t] = (k >= 1) ? ab_recip(H[(a0 + k) + (size_t)(a0 + k - 1) * l]) : mk(-1.0, 0.0);    // k = 0: rho = the sum itself
         }
         // -- G[k] = sum_{j = k_hi}^{n-1} H[k, j] P[j, :]   (rows k of the block x 128 columns, MFMA)
         kb_d4 acc_re[2][2], acc_im[2][2];
@@ -349,11 +368,16 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         // (right-looking), so a step is one dependent multiply plus independent updates, fully unrolled.
         if (wave < 2 && !(dbg & 2)) {
             const int c = wave * 64 + lane;                  // this lane's column
-            const bool isy = lane >= 32;
+            const double isyf = lane >= 32 ? 1.0 : 0.0;
             const cd z = L.z[wave * 32 + (lane & 31)];
+            // LDS addresses as ONE laundered VGPR base + compile-time offsets (ds_read_b128 ... offset:imm): left to itself
+            // the compiler materialises each of the 500 wave-uniform addresses in an SGPR, spills them to VGPR lanes and pays
+            // v_readlane + v_mov per load
+            unsigned bfb = ab_lds_addr(&L.bf[0][c]), htb = ab_lds_addr(&L.ht[0][0]), ivb = ab_lds_addr(&L.inv[0]);
+            asm volatile("" : "+v"(bfb), "+v"(htb), "+v"(ivb));
             cd rs[KB_AB_BLK];
 #pragma unroll
-            for (int r = 0; r < KB_AB_BLK; ++r) rs[r] = L.bf[r][c];
+            for (int r = 0; r < KB_AB_BLK; ++r) rs[r] = ab_lds_ld(bfb, r * (2 * KB_AB_TILE) * (int)sizeof(cd));
             cd pk = L.prow[c];                               // p_k of the step's row (own column)
             // (slots below rmin - rows k < 0 of the topmost block - run through the same code on zeros: no branches, one
             // basic block, so that the loads of the next steps' H columns are scheduled under the arithmetic of this one)
@@ -362,15 +386,16 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
                 cd hc[KB_AB_BLK];
 #pragma unroll
                 for (int rp = 0; rp < KB_AB_BLK - 1; ++rp)
-                    if (rp < r) hc[rp] = L.ht[rp][r > 0 ? r - 1 : 0];                      // H[k', k-1], rows above
-                const cd invr = L.inv[r];
+                    if (rp < r) hc[rp] = ab_lds_ld(htb, (rp * (KB_AB_BLK + 1) + (r > 0 ? r - 1 : 0)) * (int)sizeof(cd));   // H[k', k-1], rows above
+                const cd invr = ab_lds_ld(ivb, r * (int)sizeof(cd));
                 // the derivative lane needs x_k: the x lane of the same root is 32 lanes below
-                const double xkx = __shfl(pk.x, lane & 31, 64), xky = __shfl(pk.y, lane & 31, 64);
+                // (v_permlane32_swap: the upper half of the wavefront receives the lower half's value - a VALU move instead of
+                // a round trip through the LDS crossbar on the dependent chain of every step)
+                const double xkx = ab_lower_half(pk.x), xky = ab_lower_half(pk.y);
                 cd sv = rs[r] - z * pk;
-                if (isy) sv = sv - mk(xkx, xky);
-                const cd mres = -(sv * invr);
-                const bool div = kb0s + r >= 1;
-                const cd res = mk(div ? mres.x : sv.x, div ? mres.y : sv.y);
+                sv.x = fma(-isyf, xkx, sv.x);
+                sv.y = fma(-isyf, xky, sv.y);
+                const cd res = -(sv * invr);                 // (row 0 of the matrix, rho itself: inv = -1)
                 rs[r] = res;
                 pk = res;
 #pragma unroll
@@ -378,7 +403,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
                     if (rp < r) cfma(rs[rp], hc[rp], res);                                  // ... times p_{k-1}
             }
 #pragma unroll
-            for (int r = 0; r < KB_AB_BLK; ++r) L.bf[r][c] = rs[r];
+            for (int r = 0; r < KB_AB_BLK; ++r) ab_lds_st(bfb, r * (2 * KB_AB_TILE) * (int)sizeof(cd), rs[r]);
         }
         __syncthreads();
         if (kb0s <= 0) { rho_slot = rmin; break; }           // bf[rmin] holds rho (x columns) and rho' (y columns)
