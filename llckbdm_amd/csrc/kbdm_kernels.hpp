@@ -125,35 +125,37 @@ constexpr int KB_TU_PITCH = 80;   // doubles per k row in LDS
 // KFAST: the operands are read k-fastest (thread t stages k = t & 7 of rows t >> 3 and (t >> 3) + 32): for products whose
 // operands are contiguous along k in memory (A^H B: both factors column-major with k = the row index).
 typedef double kb_tu_stage[2][2][KB_TU_KC][KB_TU_PITCH];       // [A|B][re|im][k][row]; a tile product needs two (double buffer)
-template <bool STORE, bool KFAST, class FA, class FB, class FC>
-__device__ __forceinline__ void mfma_tile_ks(kb_tu_stage* s_op, FA Aop, FB Bop, FC Cptr, int NCH) {
+template <bool STORE, bool KFA, bool KFB, class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_tile_ks2(kb_tu_stage* s_op, FA Aop, FB Bop, FC Cptr, int NCH) {
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
-    // staging: thread t holds (row srow, k = sk) and (row srow + srow2, k = sk + sk2) of a chunk
-    const int srow = KFAST ? (t >> 3) : (t & 63), sk = KFAST ? (t & 7) : (t >> 6);
-    constexpr int srow2 = KFAST ? 32 : 0, sk2 = KFAST ? 0 : 4;
+    // staging: thread t holds (row srow, k = sk) and (row srow + srow2, k = sk + sk2) of a chunk, per operand
+    const int srowa = KFA ? (t >> 3) : (t & 63), ska = KFA ? (t & 7) : (t >> 6);
+    constexpr int srowa2 = KFA ? 32 : 0, ska2 = KFA ? 0 : 4;
+    const int srowb = KFB ? (t >> 3) : (t & 63), skb = KFB ? (t & 7) : (t >> 6);
+    constexpr int srowb2 = KFB ? 32 : 0, skb2 = KFB ? 0 : 4;
     kb_d4 acc_re[2][2], acc_im[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
     cd ga[2], gb[2];
-    ga[0] = Aop(srow, sk); ga[1] = Aop(srow + srow2, sk + sk2);
-    gb[0] = Bop(srow, sk); gb[1] = Bop(srow + srow2, sk + sk2);
+    ga[0] = Aop(srowa, ska); ga[1] = Aop(srowa + srowa2, ska + ska2);
+    gb[0] = Bop(srowb, skb); gb[1] = Bop(srowb + srowb2, skb + skb2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        s_op[0][0][0][sk + sk2 * j][srow + srow2 * j] = ga[j].x; s_op[0][0][1][sk + sk2 * j][srow + srow2 * j] = ga[j].y;
-        s_op[0][1][0][sk + sk2 * j][srow + srow2 * j] = gb[j].x; s_op[0][1][1][sk + sk2 * j][srow + srow2 * j] = gb[j].y;
+        s_op[0][0][0][ska + ska2 * j][srowa + srowa2 * j] = ga[j].x; s_op[0][0][1][ska + ska2 * j][srowa + srowa2 * j] = ga[j].y;
+        s_op[0][1][0][skb + skb2 * j][srowb + srowb2 * j] = gb[j].x; s_op[0][1][1][skb + skb2 * j][srowb + srowb2 * j] = gb[j].y;
     }
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < NCH) {
-            const int kn = (ch + 1) * KB_TU_KC + sk;
-            ga[0] = Aop(srow, kn); ga[1] = Aop(srow + srow2, kn + sk2);
-            gb[0] = Bop(srow, kn); gb[1] = Bop(srow + srow2, kn + sk2);
+            const int kna = (ch + 1) * KB_TU_KC + ska, knb = (ch + 1) * KB_TU_KC + skb;
+            ga[0] = Aop(srowa, kna); ga[1] = Aop(srowa + srowa2, kna + ska2);
+            gb[0] = Bop(srowb, knb); gb[1] = Bop(srowb + srowb2, knb + skb2);
         }
 #pragma unroll
         for (int ks = 0; ks < KB_TU_KC; ks += 4) {
@@ -179,8 +181,8 @@ __device__ __forceinline__ void mfma_tile_ks(kb_tu_stage* s_op, FA Aop, FB Bop, 
         if (ch + 1 < NCH) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                s_op[buf ^ 1][0][0][sk + sk2 * j][srow + srow2 * j] = ga[j].x; s_op[buf ^ 1][0][1][sk + sk2 * j][srow + srow2 * j] = ga[j].y;
-                s_op[buf ^ 1][1][0][sk + sk2 * j][srow + srow2 * j] = gb[j].x; s_op[buf ^ 1][1][1][sk + sk2 * j][srow + srow2 * j] = gb[j].y;
+                s_op[buf ^ 1][0][0][ska + ska2 * j][srowa + srowa2 * j] = ga[j].x; s_op[buf ^ 1][0][1][ska + ska2 * j][srowa + srowa2 * j] = ga[j].y;
+                s_op[buf ^ 1][1][0][skb + skb2 * j][srowb + srowb2 * j] = gb[j].x; s_op[buf ^ 1][1][1][skb + skb2 * j][srowb + srowb2 * j] = gb[j].y;
             }
         }
         __syncthreads();
@@ -206,6 +208,10 @@ __device__ __forceinline__ void mfma_tile_ks(kb_tu_stage* s_op, FA Aop, FB Bop, 
             }
 }
 
+template <bool STORE, bool KFAST, class FA, class FB, class FC>
+__device__ __forceinline__ void mfma_tile_ks(kb_tu_stage* s_op, FA Aop, FB Bop, FC Cptr, int NCH) {
+    mfma_tile_ks2<STORE, KFAST, KFAST>(s_op, Aop, Bop, Cptr, NCH);
+}
 template <bool STORE, bool KFAST, class FA, class FB, class FC>
 __device__ __forceinline__ void mfma_tile_kx(FA Aop, FB Bop, FC Cptr, int NCH) {
     __shared__ kb_tu_stage s_op[2];
@@ -395,16 +401,18 @@ __global__ void __launch_bounds__(256) k_wy_tfac(const KbItem* __restrict__ item
     __syncthreads();
     // zlarft, forward / columnwise:  T(0:i, i) = -tau_i T(0:i, 0:i) (V^H v_i)(0:i),  T(i, i) = tau_i.  In place: column i of T
     // replaces row i of G (G[i][t] <- T[t][i], t <= i); a step reads only row i of G and finished columns of T.
-    const int t = threadIdx.x;
+    // (four threads per row of the column: a step is a dot product of at most 16 terms per thread + two shuffles)
+    const int t = threadIdx.x, row = t >> 2, part = t & 3;
     for (int i = 0; i < KB_WYB; ++i) {
         const cd ti = (kb + i < g.nref) ? g.tau[kb + i] : czero();
         if (t < i) col[t] = -(ti * G[i][t]);
         __syncthreads();
-        if (t < i) {
-            cd acc = czero();
-            for (int l = t; l < i; ++l) cfma(acc, G[l][t], col[l]);
-            G[i][t] = acc;
-        }
+        cd acc = czero();
+        if (row < i)
+            for (int l = row + part; l < i; l += 4) cfma(acc, G[l][row], col[l]);
+        acc.x += __shfl_xor(acc.x, 1, 64); acc.y += __shfl_xor(acc.y, 1, 64);
+        acc.x += __shfl_xor(acc.x, 2, 64); acc.y += __shfl_xor(acc.y, 2, 64);
+        if (row < i && part == 0) G[i][row] = acc;      // (row i of G was last read before the barrier above)
         if (t == i) G[i][i] = ti;
         __syncthreads();
     }
@@ -502,9 +510,11 @@ __device__ __forceinline__ GemmArgs gemm_setup(const KbItem& it, const cd* signa
     return g;
 }
 
-constexpr int GT = 32;   // tile edge
-constexpr int GK = 16;   // k step
+constexpr int GT = 64;   // tile edge
 
+// One 64 x 64 tile of C per workgroup on FP64 MFMA (mfma_tile_ks2: operands staged through LDS in chunks of 8 k, each
+// operand in the order that is contiguous in memory); the row / column scalings go into the operands while they are
+// staged (Dsqi is applied to every term instead of to the sum: the same product up to rounding).
 template <int STAGE>
 __global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                const cd* __restrict__ signals, int N, int p, cd* arena,
@@ -513,54 +523,32 @@ __global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, 
     const GemmArgs g = gemm_setup<STAGE>(it, signals, N, p, arena, varena);
     const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
     if (i0 >= g.M || j0 >= g.N) return;
-    __shared__ cd As[GK][GT + 1];
-    __shared__ cd Bs[GK][GT + 1];
-    const int t = threadIdx.x;
-    const int tx = t & 15, ty = t >> 4;
-    cd c00 = czero(), c01 = czero(), c10 = czero(), c11 = czero();
-    for (int k0 = 0; k0 < g.K; k0 += GK) {
-        // ---- stage A tile (GT rows x GK k)
-        if (g.amode == 0) {
-            for (int e = t; e < GT * GK; e += 256) {
-                const int i = e % GT, kk = e / GT;
-                const int gi = i0 + i, gk = k0 + kk;
-                As[kk][i] = (gi < g.M && gk < g.K) ? g.A[gi + (size_t)gk * g.lda] : czero();
-            }
-        } else if (g.amode == 1) {
-            for (int e = t; e < GT * GK; e += 256) {
-                const int kk = e % GK, i = e / GK;
-                const int gi = i0 + i, gk = k0 + kk;
-                As[kk][i] = (gi < g.M && gk < g.K) ? conj(g.A[gk + (size_t)gi * g.lda]) : czero();
-            }
-        } else {
-            for (int e = t; e < GT * GK; e += 256) {
-                const int i = e % GT, kk = e / GT;
-                const int gi = i0 + i, gk = k0 + kk;
-                As[kk][i] = (gi < g.M && gk < g.K) ? g.A[gi + gk + g.shift] : czero();
-            }
-        }
-        // ---- stage B tile (GK k x GT cols)
-        for (int e = t; e < GT * GK; e += 256) {
-            const int kk = e % GK, j = e / GK;
-            const int gj = j0 + j, gk = k0 + kk;
-            Bs[kk][j] = (gj < g.N && gk < g.K) ? g.B[gk + (size_t)gj * g.ldb] : czero();
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < GK; ++kk) {
-            const cd a0 = As[kk][tx], a1 = As[kk][tx + 16];
-            const cd b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
-            cfma(c00, a0, b0); cfma(c01, a0, b1); cfma(c10, a1, b0); cfma(c11, a1, b1);
-        }
-        __syncthreads();
-    }
-    const int gi0 = i0 + tx, gi1 = i0 + tx + 16, gj0 = j0 + ty, gj1 = j0 + ty + 16;
-    const double r0 = (g.rs && gi0 < g.M) ? g.rs[gi0] : 1.0, r1 = (g.rs && gi1 < g.M) ? g.rs[gi1] : 1.0;
-    const double s0 = (g.cs && gj0 < g.N) ? g.cs[gj0] : 1.0, s1 = (g.cs && gj1 < g.N) ? g.cs[gj1] : 1.0;
-    if (gi0 < g.M && gj0 < g.N) g.C[gi0 + (size_t)gj0 * g.ldc] = (r0 * s0) * c00;
-    if (gi0 < g.M && gj1 < g.N) g.C[gi0 + (size_t)gj1 * g.ldc] = (r0 * s1) * c01;
-    if (gi1 < g.M && gj0 < g.N) g.C[gi1 + (size_t)gj0 * g.ldc] = (r1 * s0) * c10;
-    if (gi1 < g.M && gj1 < g.N) g.C[gi1 + (size_t)gj1 * g.ldc] = (r1 * s1) * c11;
+    __shared__ kb_tu_stage s_op[2];
+    constexpr int AMODE = (STAGE == 1 || STAGE == 5) ? 2 : (STAGE == 2 ? 1 : 0);
+    constexpr bool KFA = AMODE != 0;                 // A^H and the Hankel operand are contiguous along k, a plain A along rows
+    const int nch = (g.K + KB_TU_KC - 1) / KB_TU_KC;
+    mfma_tile_ks2<true, KFA, true>(
+        s_op,
+        [&](int i, int k) -> cd {
+            const int gi = i0 + i;
+            if (gi >= g.M || k >= g.K) return czero();
+            cd a;
+            if (AMODE == 0) a = g.A[gi + (size_t)k * g.lda];
+            else if (AMODE == 1) a = conj(g.A[k + (size_t)gi * g.lda]);
+            else a = g.A[gi + k + g.shift];
+            return g.rs ? g.rs[gi] * a : a;
+        },
+        [&](int j, int k) -> cd {                      // the tile computes sum_k Aop(i, k) conj(Bop(j, k))
+            const int gj = j0 + j;
+            if (gj >= g.N || k >= g.K) return czero();
+            const cd b = conj(g.B[k + (size_t)gj * g.ldb]);
+            return g.cs ? g.cs[gj] * b : b;
+        },
+        [&](int i, int j) -> cd* {
+            const int gi = i0 + i, gj = j0 + j;
+            return (gi < g.M && gj < g.N) ? &g.C[gi + (size_t)gj * g.ldc] : nullptr;
+        },
+        nch);
 }
 
 
