@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kb_aberth.hpp"
 #include "kbdm_device.h"
 
@@ -306,30 +308,39 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             for (int y = 0; y < 2; ++y) { acc_re[x][y] = (kb_d4){0, 0, 0, 0}; acc_im[x][y] = (kb_d4){0, 0, 0, 0}; }
         const int K = n - k_hi;                              // stored rows j = k_hi .. n-1
         const int nch = (K + KB_AB_KC - 1) / KB_AB_KC;
-        // staging: A: thread -> (row ar, k ak);  B: thread -> column bc, rows bk, bk+2, bk+4, bk+6
+        // staging: A: thread -> (row ar, k ak);  B: thread -> column bc, rows bk, bk+2, bk+4, bk+6.  Chunks of 8 rows j from
+        // the OLDEST (j = n-1 ..) to the newest (the rows the previous block has just stored come last); the global loads run
+        // TWO chunks ahead of the MFMAs (two register sets): a chunk's product is shorter than an L2 round trip.  Loads are
+        // unconditional (addresses clamped into the stored rows, the value masked when it is staged): no branch between a
+        // load and its use, so the compiler counts the outstanding loads instead of draining them.
         const int ar = t & 31, ak = t >> 5;
+        const int arc = ar >= rmin ? ar : rmin;
         const int bc = t & 127, bk = t >> 7;
-        cd ga, gb[4];
-        auto fetch = [&](int ch) {
-            const int j = k_hi + ch * KB_AB_KC;
-            ga = (ar >= rmin && j + ak < n) ? H[(a0 + kb0s + ar) + (size_t)(a0 + j + ak) * l] : czero();
+        cd ga[2], gb[2][4];
+        auto fetch = [&](int ch, auto SET) {
+            constexpr int set = decltype(SET)::value;
+            const int jb = n - (ch + 1) * KB_AB_KC;          // rows jb .. jb + 7 (those below k_hi do not exist yet)
+            const int ja = jb + ak;
+            ga[set] = H[(a0 + kb0s + arc) + (size_t)(a0 + (ja >= k_hi ? ja : k_hi)) * l];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int jj = j + bk + 2 * q;
-                gb[q] = (jj < n) ? P[(size_t)jj * (2 * KB_AB_TILE) + bc] : czero();
+                const int jj = jb + bk + 2 * q;
+                gb[set][q] = P[(size_t)(jj >= k_hi ? jj : k_hi) * (2 * KB_AB_TILE) + bc];
             }
         };
-        auto stage = [&](int buf) {
-            L.sa[buf][0][ak][ar] = ga.x; L.sa[buf][1][ak][ar] = ga.y;
+        auto stage = [&](int ch, int buf, auto SET) {
+            constexpr int set = decltype(SET)::value;
+            const int jb = n - (ch + 1) * KB_AB_KC;
+            const bool va = ar >= rmin && jb + ak >= k_hi;
+            L.sa[buf][0][ak][ar] = va ? ga[set].x : 0.0; L.sa[buf][1][ak][ar] = va ? ga[set].y : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { L.sb[buf][0][bk + 2 * q][bc] = gb[q].x; L.sb[buf][1][bk + 2 * q][bc] = gb[q].y; }
+            for (int q = 0; q < 4; ++q) {
+                const bool vb = jb + bk + 2 * q >= k_hi;
+                L.sb[buf][0][bk + 2 * q][bc] = vb ? gb[set][q].x : 0.0; L.sb[buf][1][bk + 2 * q][bc] = vb ? gb[set][q].y : 0.0;
+            }
         };
-        fetch(0);
-        stage(0);
-        __syncthreads();
-        for (int ch = 0; ch < ((dbg & 1) ? 0 : nch); ++ch) {
-            const int buf = ch & 1;
-            if (ch + 1 < nch) fetch(ch + 1);
+        auto product = [&](int buf) {
+            if (dbg & 1) return;
 #pragma unroll
             for (int ks = 0; ks < KB_AB_KC; ks += 4) {
                 double are[2], aim[2], bre[2], bim[2];
@@ -351,7 +362,23 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
                         acc_im[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[rb], bre[cb], acc_im[rb][cb], 0, 0, 0);
                     }
             }
-            if (ch + 1 < nch) stage(buf ^ 1);
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        fetch(0, S0{});
+        fetch(1, S1{});
+        stage(0, 0, S0{});
+        __syncthreads();
+        for (int ch = 0; ch < nch; ch += 2) {
+            // chunk ch is staged in buffer 0 (from set 0), chunk ch + 1 is in flight in set 1
+            fetch(ch + 2, S0{});
+            product(0);
+            if (ch + 1 < nch) stage(ch + 1, 1, S1{});
+            __syncthreads();
+            if (ch + 1 >= nch) break;
+            fetch(ch + 3, S1{});
+            product(1);
+            if (ch + 2 < nch) stage(ch + 2, 0, S0{});
             __syncthreads();
         }
         // D element of lane (li, lk), register g: row = rb*16 + lk + 4 g, column = wave*32 + cb*16 + li
