@@ -31,7 +31,8 @@ struct AbLds {                                  // dynamic LDS of k_ab_iter
     kb::cd bf[KB_AB_BLK][2 * KB_AB_TILE];       // block rows x 128 columns: G, then the finished rows
     kb::cd ht[KB_AB_BLK][KB_AB_BLK + 1];        // the block's triangle of H (row k, column j), padded
     kb::cd inv[KB_AB_BLK];                      // 1 / H[k, k-1]
-    kb::cd prow[2 * KB_AB_TILE];                // the finished row above the block (x_{k_hi}, y_{k_hi})
+    kb::cd prow[2 * KB_AB_TILE];                // the finished row above the block (x_{k_hi}, y_{k_hi}); at the end rho, rho'
+    double fac[2 * KB_AB_TILE];                 // power-of-two rescaling of a column at the end of a block
     kb::cd z[KB_AB_TILE];
     kb::cd S[KB_AB_TILE];
     double part[4][KB_AB_TILE][2];
@@ -241,16 +242,28 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     const int nr = (nactive - tile * KB_AB_TILE < KB_AB_TILE) ? nactive - tile * KB_AB_TILE : KB_AB_TILE;
     if (nr <= 0) return;                                    // this tile has nothing left to iterate
     if (abstat && t == 0) atomicAdd(&abstat[step * KB_AB_BUDGET + iter], 1);
-    if (t < KB_AB_TILE) {
-        cd z = mk(0.0, 0.0);
-        if (t < nr) {
-            z = zin[L.ridx[t]];
-            if (iter == 0) z = ab_perturb(z, a0 + L.ridx[t], hnorm);
-        }
-        L.z[t] = z;
+    // (diagnostic, dbg & 8: 10 ns ticks per phase of the full tiles of nodes with more than 256 rows, rows 8.. of abstat)
+    const bool prof = (dbg & 8) && abstat && t == 0 && nr == KB_AB_TILE && n > 256;
+    long long tp = prof ? wall_clock64() : 0;
+    auto lap = [&](int ph) {
+        if (!prof) return;
+        const long long now = wall_clock64();
+        atomicAdd(&abstat[8 * KB_AB_BUDGET + ph], (int)(now - tp));
+        tp = now;
+    };
+    // Panel P[row][128] of this tile in global memory.  In the first iteration of a level its first rows hold the separated
+    // starting values of the whole node (computed once per tile instead of once per pair of roots: ab_perturb costs a sincos)
+    cd* P = ws.panel + ((size_t)a0 * Tl + (size_t)tile * n) * (2 * KB_AB_TILE);
+    const cd* zsrc = zin;
+    if (iter == 0) {
+        for (int j = t; j < n; j += 256) P[j] = ab_perturb(zin[j], a0 + j, hnorm);
+        zsrc = P;
+        __syncthreads();
     }
+    if (t < KB_AB_TILE) L.z[t] = (t < nr) ? zsrc[L.ridx[t]] : mk(0.0, 0.0);
     __syncthreads();
-    // ---- repulsion sums S_i = sum_{j != i} 1 / (z_i - z_j) over the node (four threads per root)
+    // ---- repulsion sums S_i = sum_{j != i} 1 / (z_i - z_j) over the node (four threads per root).  S only steers the
+    // iteration (its fixed points are the roots whatever S is): hardware reciprocal + one Newton step instead of divisions
     {
         const int i = t & 63, q = t >> 6;
         double sx = 0.0, sy = 0.0;
@@ -259,11 +272,11 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             const int me = L.ridx[i];
             for (int j = q; j < n; j += 4) {
                 if (j == me) continue;
-                cd zj = zin[j];
-                if (iter == 0) zj = ab_perturb(zj, a0 + j, hnorm);
-                const cd d = zi - zj;
+                const cd d = zi - zsrc[j];
                 const double den = d.x * d.x + d.y * d.y;
-                sx += d.x / den; sy -= d.y / den;
+                double inv = __builtin_amdgcn_rcp(den);
+                inv = inv * fma(-den, inv, 2.0);
+                sx = fma(d.x, inv, sx); sy = fma(-d.y, inv, sy);
             }
         }
         L.part[q][i][0] = sx; L.part[q][i][1] = sy;
@@ -272,9 +285,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     if (t < KB_AB_TILE)
         L.S[t] = mk((L.part[0][t][0] + L.part[1][t][0]) + (L.part[2][t][0] + L.part[3][t][0]),
                     (L.part[0][t][1] + L.part[1][t][1]) + (L.part[2][t][1] + L.part[3][t][1]));
-    // ---- Hyman's recurrence, rows n-1 .. 0, blocks of 32 rows.  Panel P[row][128] in global memory.
-    const int Tlrows = Tl;
-    cd* P = ws.panel + ((size_t)a0 * Tlrows + (size_t)tile * n) * (2 * KB_AB_TILE);
+    // ---- Hyman's recurrence, rows n-1 .. 0, blocks of 32 rows
     const int wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lk = lane >> 4;
     if (t < 2 * KB_AB_TILE) {                               // row n-1: x = 1, y = 0
@@ -285,20 +296,24 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     }
     __syncthreads();
     int k_hi = n - 1;
-    int rho_slot = 0;
+    lap(0);
     while (k_hi >= 0) {
         // slot r of the block <-> row k = kb0s + r of the node, r = 0 .. 31; the topmost block has kb0s <= 0 and its
         // slots below rmin are empty (k < 0)
         const int kb0s = k_hi - (KB_AB_BLK - 1);
         const int rmin = kb0s < 0 ? -kb0s : 0;
-        // -- the block's triangle of H and the reciprocal subdiagonals
-        for (int e = t; e < KB_AB_BLK * KB_AB_BLK; e += 256) {
-            const int r = e & 31, j = e >> 5;
-            L.ht[r][j] = (r >= rmin && j >= rmin && j >= r - 1) ? H[(a0 + kb0s + r) + (size_t)(a0 + kb0s + j) * l] : czero();
+        // -- the block's triangle of H and the subdiagonals: loaded now, written to LDS after the block product (the loads
+        // travel under the product instead of in front of it)
+        cd htr[KB_AB_BLK * KB_AB_BLK / 256], hsub = mk(1.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < KB_AB_BLK * KB_AB_BLK / 256; ++i) {
+            const int e = t + 256 * i, r = e & 31, j = e >> 5;
+            const int rc = r >= rmin ? r : rmin, jc = j >= rmin ? j : rmin;
+            htr[i] = H[(a0 + kb0s + rc) + (size_t)(a0 + kb0s + jc) * l];
         }
         if (t < KB_AB_BLK) {
             const int k = kb0s + t;
-            L.inv[t] = (k >= 1) ? ab_recip(H[(a0 + k) + (size_t)(a0 + k - 1) * l]) : mk(-1.0, 0.0);    // k = 0: rho = the sum itself
+            hsub = H[(a0 + (k >= 1 ? k : 1)) + (size_t)(a0 + (k >= 1 ? k : 1) - 1) * l];
         }
         // -- G[k] = sum_{j = k_hi}^{n-1} H[k, j] P[j, :]   (rows k of the block x 128 columns, MFMA)
         kb_d4 acc_re[2][2], acc_im[2][2];
@@ -317,26 +332,38 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         const int arc = ar >= rmin ? ar : rmin;
         const int bc = t & 127, bk = t >> 7;
         cd ga[2], gb[2][4];
+        // (32-bit element offsets from uniform bases: one v_max + one shift-add per load instead of 64-bit address arithmetic -
+        // every instruction of this loop that is not an MFMA is issued in front of the MFMAs, not under them)
+        const cd* Hblk = H + (size_t)a0 * l + (a0 + kb0s);          // H[kb0s + r, j] of the node = Hblk[r + j * l]
+        const unsigned offa0 = (unsigned)arc, offb0 = (unsigned)bc;
         auto fetch = [&](int ch, auto SET) {
             constexpr int set = decltype(SET)::value;
-            const int jb = n - (ch + 1) * KB_AB_KC;          // rows jb .. jb + 7 (those below k_hi do not exist yet)
+            const int chc = ch < nch ? ch : nch - 1;         // (the prefetch runs past the last chunk: stay inside the panel)
+            const int jb = n - (chc + 1) * KB_AB_KC;         // rows jb .. jb + 7 (those below k_hi do not exist yet)
             const int ja = jb + ak;
-            ga[set] = H[(a0 + kb0s + arc) + (size_t)(a0 + (ja >= k_hi ? ja : k_hi)) * l];
+            ga[set] = Hblk[offa0 + (unsigned)(ja >= k_hi ? ja : k_hi) * (unsigned)l];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int jj = jb + bk + 2 * q;
-                gb[set][q] = P[(size_t)(jj >= k_hi ? jj : k_hi) * (2 * KB_AB_TILE) + bc];
+                gb[set][q] = P[offb0 + (unsigned)(jj >= k_hi ? jj : k_hi) * (unsigned)(2 * KB_AB_TILE)];
             }
         };
         auto stage = [&](int ch, int buf, auto SET) {
             constexpr int set = decltype(SET)::value;
             const int jb = n - (ch + 1) * KB_AB_KC;
-            const bool va = ar >= rmin && jb + ak >= k_hi;
-            L.sa[buf][0][ak][ar] = va ? ga[set].x : 0.0; L.sa[buf][1][ak][ar] = va ? ga[set].y : 0.0;
+            if (jb >= k_hi) {                                // a full chunk: nothing to mask (empty slots of the topmost block
+                                                             // read a clamped row of H: their sums are never used)
+                L.sa[buf][0][ak][ar] = ga[set].x; L.sa[buf][1][ak][ar] = ga[set].y;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool vb = jb + bk + 2 * q >= k_hi;
-                L.sb[buf][0][bk + 2 * q][bc] = vb ? gb[set][q].x : 0.0; L.sb[buf][1][bk + 2 * q][bc] = vb ? gb[set][q].y : 0.0;
+                for (int q = 0; q < 4; ++q) { L.sb[buf][0][bk + 2 * q][bc] = gb[set][q].x; L.sb[buf][1][bk + 2 * q][bc] = gb[set][q].y; }
+            } else {
+                const bool va = jb + ak >= k_hi;
+                L.sa[buf][0][ak][ar] = va ? ga[set].x : 0.0; L.sa[buf][1][ak][ar] = va ? ga[set].y : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool vb = jb + bk + 2 * q >= k_hi;
+                    L.sb[buf][0][bk + 2 * q][bc] = vb ? gb[set][q].x : 0.0; L.sb[buf][1][bk + 2 * q][bc] = vb ? gb[set][q].y : 0.0;
+                }
             }
         };
         auto product = [&](int buf) {
@@ -365,6 +392,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
+        lap(1);
         fetch(0, S0{});
         fetch(1, S1{});
         stage(0, 0, S0{});
@@ -381,6 +409,13 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             if (ch + 2 < nch) stage(ch + 2, 0, S0{});
             __syncthreads();
         }
+        lap(2);
+#pragma unroll
+        for (int i = 0; i < KB_AB_BLK * KB_AB_BLK / 256; ++i) {
+            const int e = t + 256 * i, r = e & 31, j = e >> 5;
+            L.ht[r][j] = (r >= rmin && j >= rmin && j >= r - 1) ? htr[i] : czero();
+        }
+        if (t < KB_AB_BLK) L.inv[t] = (kb0s + t >= 1) ? ab_recip(hsub) : mk(-1.0, 0.0);      // k = 0: rho = the sum itself
         // D element of lane (li, lk), register g: row = rb*16 + lk + 4 g, column = wave*32 + cb*16 + li
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -390,6 +425,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
                 for (int g = 0; g < 4; ++g)
                     L.bf[rb * 16 + lk + 4 * g][wave * 32 + cb * 16 + li] = mk(acc_re[rb][cb][g], acc_im[rb][cb][g]);
         __syncthreads();
+        lap(3);
         // -- the triangle, two wavefronts (each 32 roots: lanes 0-31 x, lanes 32-63 the derivative): the running sums of
         // all 32 rows of a column live in REGISTERS; as soon as p_{k-1} is known it is added into the rows above
         // (right-looking), so a step is one dependent multiply plus independent updates, fully unrolled.
@@ -429,57 +465,52 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
                 for (int rp = 0; rp < KB_AB_BLK - 1; ++rp)
                     if (rp < r) cfma(rs[rp], hc[rp], res);                                  // ... times p_{k-1}
             }
+            if (kb0s <= 0) {                                 // the topmost block: slot rmin holds rho (x lanes) and rho' (y lanes)
+                cd rho = rs[0];
 #pragma unroll
-            for (int r = 0; r < KB_AB_BLK; ++r) ab_lds_st(bfb, r * (2 * KB_AB_TILE) * (int)sizeof(cd), rs[r]);
+                for (int r = 1; r < KB_AB_BLK; ++r)
+                    if (r == rmin) rho = rs[r];
+                L.prow[c] = rho;
+            } else {
+                // the finished rows kb0s-1 .. k_hi-1 straight from the registers (a row of 64 columns is 1 KB contiguous),
+                // the row above the next block, and the power-of-two rescaling of a column whose newest x has grown or
+                // shrunk a lot (decided on the x lane, shared with the derivative lane of the same root)
+#pragma unroll
+                for (int r = 0; r < KB_AB_BLK; ++r)
+                    if (!(dbg & 4)) P[(size_t)(kb0s + r - 1) * (2 * KB_AB_TILE) + c] = rs[r];
+                const double mx = fmax(fabs(rs[0].x), fabs(rs[0].y));
+                int e = 0;
+                if (mx > 0.0 && mx == mx && mx < 1.79769313486231570815e308) (void)frexp(mx, &e);
+                const double f = ab_lower_half((e > 60 || e < -60) ? ldexp(1.0, -e) : 1.0);
+                L.prow[c] = f * rs[0];
+                L.fac[c] = f;
+                if (f != 1.0) L.flags[1] = 1;
+            }
         }
         __syncthreads();
-        if (kb0s <= 0) { rho_slot = rmin; break; }           // bf[rmin] holds rho (x columns) and rho' (y columns)
-        // -- store the finished rows kb0s-1 .. k_hi-1, rescale the columns if they have grown or shrunk a lot
-        if (t < 2 * KB_AB_TILE) {
-            const int c = t;
-            const cd top = L.bf[0][c];
-            L.prow[c] = top;
-        }
-        for (int e = t; e < KB_AB_BLK * 2 * KB_AB_TILE; e += 256) {
-            const int r = e >> 7, c = e & 127;
-            P[(size_t)(kb0s + r - 1) * (2 * KB_AB_TILE) + c] = L.bf[r][c];
-        }
-        if (t < KB_AB_TILE) {                                // scale decision per root from |x| of the newest row
-            const int cxx = ab_col(t, 0);
-            const cd v = L.bf[0][cxx];
-            const double mx = fmax(fabs(v.x), fabs(v.y));
-            int e = 0;
-            if (mx > 0.0 && mx == mx && mx < 1.79769313486231570815e308) (void)frexp(mx, &e);
-            L.part[0][t][0] = (e > 60 || e < -60) ? ldexp(1.0, -e) : 1.0;
-            if (e > 60 || e < -60) L.flags[1] = 1;
-        }
-        __syncthreads();
+        lap(4);
+        if (kb0s <= 0) break;
         if (L.flags[1]) {
             // all finished rows of the rescaled columns (kb0s-1 .. n-1), both x and y
             for (size_t e = t; e < (size_t)(n - (kb0s - 1)) * 2 * KB_AB_TILE; e += 256) {
-                const int c = (int)(e & 127);
-                const int root = (c >> 6) * 32 + (c & 31);
-                const double f = L.part[0][root][0];
+                const double f = L.fac[e & (2 * KB_AB_TILE - 1)];
                 if (f != 1.0) {
                     cd* p = &P[(size_t)(kb0s - 1) * (2 * KB_AB_TILE) + e];
                     *p = f * (*p);
                 }
             }
-            if (t < 2 * KB_AB_TILE) {
-                const int root = (t >> 6) * 32 + (t & 31);
-                L.prow[t] = L.part[0][root][0] * L.prow[t];
-            }
             __syncthreads();
             if (t == 0) L.flags[1] = 0;
-            __threadfence_block();
+            __syncthreads();
         }
-        __syncthreads();
         k_hi = kb0s - 1;
+        lap(5);
     }
+    if (prof) atomicAdd(&abstat[8 * KB_AB_BUDGET + 23], 1);
     // ---- the Aberth update of this tile's roots
     if (t < nr) {
         const int root = t, j = L.ridx[t];
-        const cd rho = L.bf[rho_slot][ab_col(root, 0)], rhop = L.bf[rho_slot][ab_col(root, 1)];
+        const cd rho = L.prow[ab_col(root, 0)], rhop = L.prow[ab_col(root, 1)];
         double dz;
         const cd zn = ab_update(L.z[root], rho, rhop, L.S[root], &dz);
         zout[j] = zn;
