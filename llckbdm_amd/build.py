@@ -24,8 +24,11 @@ def build_library(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs (gfx90a+ register file).  Kernels whose accumulators are
+    # loop-carried AND whose other phases fill the VGPR budget (k_ab_iter) otherwise copy 64 accumulator registers to the
+    # AGPRs and back in every iteration of the product loop.
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -23,11 +23,9 @@
 constexpr int KB_AB_KC = 8;                     // k per staged chunk of the block product
 constexpr int KB_AB_PA = 48;                    // LDS pitch (doubles) of the H chunk rows: 2 * pitch = 32 mod 64 banks, so the two k rows
                                                 // of a half-wavefront's ds_read_b64 fall on disjoint banks
-constexpr int KB_AB_PB = 144;                   // LDS pitch (doubles) of the panel chunk rows (128 columns; same bank rule)
 
 struct AbLds {                                  // dynamic LDS of k_ab_iter
-    double sa[2][2][KB_AB_KC][KB_AB_PA];        // [buffer][re|im][k][row]       H chunk
-    double sb[2][2][KB_AB_KC][KB_AB_PB];        // [buffer][re|im][k][column]    panel chunk
+    double stage[4][2][2][KB_AB_KC][KB_AB_PA];  // [wavefront][H chunk | panel chunk][re|im][k][row / column]: private staging areas
     kb::cd bf[KB_AB_BLK][2 * KB_AB_TILE];       // block rows x 128 columns: G, then the finished rows
     kb::cd ht[KB_AB_BLK][KB_AB_BLK + 1];        // the block's triangle of H (row k, column j), padded
     kb::cd inv[KB_AB_BLK];                      // 1 / H[k, k-1]
@@ -323,92 +321,111 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             for (int y = 0; y < 2; ++y) { acc_re[x][y] = (kb_d4){0, 0, 0, 0}; acc_im[x][y] = (kb_d4){0, 0, 0, 0}; }
         const int K = n - k_hi;                              // stored rows j = k_hi .. n-1
         const int nch = (K + KB_AB_KC - 1) / KB_AB_KC;
-        // staging: A: thread -> (row ar, k ak);  B: thread -> column bc, rows bk, bk+2, bk+4, bk+6.  Chunks of 8 rows j from
-        // the OLDEST (j = n-1 ..) to the newest (the rows the previous block has just stored come last); the global loads run
-        // TWO chunks ahead of the MFMAs (two register sets): a chunk's product is shorter than an L2 round trip.  Loads are
-        // unconditional (addresses clamped into the stored rows, the value masked when it is staged): no branch between a
-        // load and its use, so the compiler counts the outstanding loads instead of draining them.
-        const int ar = t & 31, ak = t >> 5;
-        const int arc = ar >= rmin ? ar : rmin;
-        const int bc = t & 127, bk = t >> 7;
-        cd ga[2], gb[2][4];
-        // (32-bit element offsets from uniform bases: one v_max + one shift-add per load instead of 64-bit address arithmetic -
-        // every instruction of this loop that is not an MFMA is issued in front of the MFMAs, not under them)
+        // Chunks of 8 rows j from the OLDEST (j = n-1 ..) to the newest (the rows the previous block has just stored come
+        // last).  Every wavefront runs its OWN pipeline - no workgroup barrier inside the product: it stages the H chunk
+        // (32 rows x 8 k; four copies per workgroup, out of the L1) and the 32 panel columns it multiplies into a private LDS
+        // area (one buffer: the DS operations of a wavefront execute in order), with the global loads two chunks ahead in two
+        // register sets.  Loads are unconditional (chunk index and rows clamped into the stored rows, the value masked when it
+        // is written to LDS): no branch between a load and its use, so the compiler counts the outstanding loads.
+        // lane -> (row / column sr, k = sk + 2 i): 32 lanes read 512 contiguous bytes
+        const int sr = lane & 31, sk = lane >> 5;
+        const int src = sr >= rmin ? sr : rmin;
+        double (*Wa)[KB_AB_KC][KB_AB_PA] = reinterpret_cast<double (*)[KB_AB_KC][KB_AB_PA]>(&L.stage[wave][0][0][0][0]);    // [re|im][k][row]
+        double (*Wb)[KB_AB_KC][KB_AB_PA] = reinterpret_cast<double (*)[KB_AB_KC][KB_AB_PA]>(&L.stage[wave][1][0][0][0]);    // [re|im][k][column]
         const cd* Hblk = H + (size_t)a0 * l + (a0 + kb0s);          // H[kb0s + r, j] of the node = Hblk[r + j * l]
-        const unsigned offa0 = (unsigned)arc, offb0 = (unsigned)bc;
+        const unsigned offa0 = (unsigned)src, offb0 = (unsigned)(wave * 32 + sr);
+        cd ga[2][4] = {}, gb[2][4] = {};
         auto fetch = [&](int ch, auto SET) {
             constexpr int set = decltype(SET)::value;
             const int chc = ch < nch ? ch : nch - 1;         // (the prefetch runs past the last chunk: stay inside the panel)
             const int jb = n - (chc + 1) * KB_AB_KC;         // rows jb .. jb + 7 (those below k_hi do not exist yet)
-            const int ja = jb + ak;
-            ga[set] = Hblk[offa0 + (unsigned)(ja >= k_hi ? ja : k_hi) * (unsigned)l];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int jj = jb + bk + 2 * q;
-                gb[set][q] = P[offb0 + (unsigned)(jj >= k_hi ? jj : k_hi) * (unsigned)(2 * KB_AB_TILE)];
+                const int jj = jb + sk + 2 * q;
+                const unsigned jc = (unsigned)(jj >= k_hi ? jj : k_hi);
+                ga[set][q] = Hblk[offa0 + jc * (unsigned)l];
+                gb[set][q] = P[offb0 + jc * (unsigned)(2 * KB_AB_TILE)];
             }
         };
-        auto stage = [&](int ch, int buf, auto SET) {
+        auto stage = [&](int ch, auto SET) {
             constexpr int set = decltype(SET)::value;
+            // (branch-free: only the H operand is masked - a zero there annihilates the clamped, finite panel row; a chunk
+            // past the last one is staged again and never multiplied)
             const int jb = n - (ch + 1) * KB_AB_KC;
-            if (jb >= k_hi) {                                // a full chunk: nothing to mask (empty slots of the topmost block
-                                                             // read a clamped row of H: their sums are never used)
-                L.sa[buf][0][ak][ar] = ga[set].x; L.sa[buf][1][ak][ar] = ga[set].y;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { L.sb[buf][0][bk + 2 * q][bc] = gb[set][q].x; L.sb[buf][1][bk + 2 * q][bc] = gb[set][q].y; }
-            } else {
-                const bool va = jb + ak >= k_hi;
-                L.sa[buf][0][ak][ar] = va ? ga[set].x : 0.0; L.sa[buf][1][ak][ar] = va ? ga[set].y : 0.0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool vb = jb + bk + 2 * q >= k_hi;
-                    L.sb[buf][0][bk + 2 * q][bc] = vb ? gb[set][q].x : 0.0; L.sb[buf][1][bk + 2 * q][bc] = vb ? gb[set][q].y : 0.0;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const bool v = jb + sk + 2 * q >= k_hi;
+                Wa[0][sk + 2 * q][sr] = v ? ga[set][q].x : 0.0; Wa[1][sk + 2 * q][sr] = v ? ga[set][q].y : 0.0;
+                Wb[0][sk + 2 * q][sr] = gb[set][q].x; Wb[1][sk + 2 * q][sr] = gb[set][q].y;
             }
         };
-        auto product = [&](int buf) {
-            if (dbg & 1) return;
+        double are[2][2] = {}, aim[2][2] = {}, bre[2][2] = {}, bim[2][2] = {};   // [ks half][tile]
+        auto operands = [&]() {
 #pragma unroll
-            for (int ks = 0; ks < KB_AB_KC; ks += 4) {
-                double are[2], aim[2], bre[2], bim[2];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
-                    are[x] = L.sa[buf][0][ks + lk][x * 16 + li];
-                    aim[x] = L.sa[buf][1][ks + lk][x * 16 + li];
-                    bre[x] = L.sb[buf][0][ks + lk][wave * 32 + x * 16 + li];
-                    bim[x] = L.sb[buf][1][ks + lk][wave * 32 + x * 16 + li];
+                    are[h][x] = Wa[0][4 * h + lk][x * 16 + li];
+                    aim[h][x] = Wa[1][4 * h + lk][x * 16 + li];
+                    bre[h][x] = Wb[0][4 * h + lk][x * 16 + li];
+                    bim[h][x] = Wb[1][4 * h + lk][x * 16 + li];
                 }
+        };
+        auto product = [&]() {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
                         // D[row][col] += A[row][k] B[k][col]: MFMA A operand = H (row = li), B operand = panel (col = li)
-                        acc_re[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[rb], bre[cb], acc_re[rb][cb], 0, 0, 0);
-                        acc_re[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[rb], bim[cb], acc_re[rb][cb], 0, 0, 0);
-                        acc_im[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[rb], bim[cb], acc_im[rb][cb], 0, 0, 0);
-                        acc_im[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[rb], bre[cb], acc_im[rb][cb], 0, 0, 0);
+                        acc_re[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[h][rb], bre[h][cb], acc_re[rb][cb], 0, 0, 0);
+                        acc_re[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[h][rb], bim[h][cb], acc_re[rb][cb], 0, 0, 0);
+                        acc_im[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[h][rb], bim[h][cb], acc_im[rb][cb], 0, 0, 0);
+                        acc_im[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[h][rb], bre[h][cb], acc_im[rb][cb], 0, 0, 0);
                     }
-            }
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
         lap(1);
         fetch(0, S0{});
         fetch(1, S1{});
-        stage(0, 0, S0{});
-        __syncthreads();
-        for (int ch = 0; ch < nch; ch += 2) {
-            // chunk ch is staged in buffer 0 (from set 0), chunk ch + 1 is in flight in set 1
-            fetch(ch + 2, S0{});
-            product(0);
-            if (ch + 1 < nch) stage(ch + 1, 1, S1{});
-            __syncthreads();
-            if (ch + 1 >= nch) break;
-            fetch(ch + 3, S1{});
-            product(1);
-            if (ch + 2 < nch) stage(ch + 2, 0, S0{});
-            __syncthreads();
+        stage(0, S0{});
+        // (one basic block per chunk; the scheduling hints spread the LDS writes of the next chunk and the global loads of
+        // the one after it between the MFMAs instead of in front of them: 8 x {4 MFMA, 2 DS write, 1 VMEM read})
+#define KB_AB_INTERLEAVE()                                                   \
+        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);               \
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);               \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               \
         }
+        int ch = 0;
+        for (; ch + 1 < nch; ch += 2) {
+            // the LDS area holds chunk ch (from set 0), chunk ch + 1 is in flight in set 1
+            __builtin_amdgcn_wave_barrier();
+            operands();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            stage(ch + 1, S1{});
+            fetch(ch + 2, S0{});
+            product();
+            KB_AB_INTERLEAVE()
+            __builtin_amdgcn_wave_barrier();
+            operands();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            stage(ch + 2, S0{});
+            fetch(ch + 3, S1{});
+            product();
+            KB_AB_INTERLEAVE()
+        }
+        if (ch < nch) {                                      // (the number of chunks of a block is odd: 1 + 32 b rows)
+            __builtin_amdgcn_wave_barrier();
+            operands();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            product();
+        }
+#undef KB_AB_INTERLEAVE
         lap(2);
 #pragma unroll
         for (int i = 0; i < KB_AB_BLK * KB_AB_BLK / 256; ++i) {

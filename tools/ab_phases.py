@@ -1,6 +1,6 @@
 """GPU: wall-clock split of a full k_ab_iter tile (KBDM_AB_DBG=8 instrumentation) on the C2 ensemble."""
 import os, sys
-os.environ["KBDM_AB_DBG"] = "8"
+os.environ["KBDM_AB_DBG"] = str(8 | int(sys.argv[1]) if len(sys.argv) > 1 else 8)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from llckbdm_amd import datasets
