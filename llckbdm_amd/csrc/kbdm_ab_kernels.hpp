@@ -343,8 +343,9 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             for (int q = 0; q < 4; ++q) {
                 const int jj = jb + sk + 2 * q;
                 const unsigned jc = (unsigned)(jj >= k_hi ? jj : k_hi);
-                ga[set][q] = Hblk[offa0 + jc * (unsigned)l];
-                gb[set][q] = P[offb0 + jc * (unsigned)(2 * KB_AB_TILE)];
+                // (32-bit BYTE offsets from the uniform bases: scalar base + vector offset addressing, two instructions per load)
+                ga[set][q] = *reinterpret_cast<const cd*>(reinterpret_cast<const char*>(Hblk) + ((__umul24(jc, (unsigned)l) + offa0) << 4));
+                gb[set][q] = *reinterpret_cast<const cd*>(reinterpret_cast<const char*>(P) + (((jc << 7) + offb0) << 4));
             }
         };
         auto stage = [&](int ch, auto SET) {
