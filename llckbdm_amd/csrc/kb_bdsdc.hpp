@@ -108,30 +108,39 @@ KB_HD void dc_leaf(const C& ctx, const double* d, const double* e, int m, DcNode
     fro = ctx.block_sum(fro);
     const double thr2 = (KB_EPS * KB_EPS) * fro;          // squared norm of a negligible column
     const int ce = (c + 1) & ~1;               // players of the round-robin (an extra dummy when c is odd)
+    // A pair of columns is rotated by C::QUAD adjacent lanes (device: four, each a quarter of the rows; the dot products
+    // meet in a DPP butterfly, so the four lanes decide on identical bits), the pairs of a round by different lane groups
+    const int LP = C::QUAD, sub = t % LP, slot = t / LP, nslot = (T / LP) > 0 ? T / LP : 1;
     for (int sweep = 0; sweep < 60; ++sweep) {
         int rotated = 0;
         for (int rd = 0; rd < ce - 1; ++rd) {
-            for (int pr = t; pr < ce / 2; pr += T) {
-                int p, q;
-                if (pr == 0) { p = ce - 1; q = rd; }
-                else { p = (rd + pr) % (ce - 1); q = (rd - pr + (ce - 1)) % (ce - 1); }
-                if (p > q) { const int x = p; p = q; q = x; }
-                if (q >= c) continue;
+            for (int pr0 = 0; pr0 < ce / 2; pr0 += nslot) {               // (uniform trip count: the butterfly needs every lane)
+                const int pr = pr0 + slot;
+                bool act = pr < ce / 2;
+                int p = 0, q = 0;
+                if (act) {
+                    if (pr == 0) { p = ce - 1; q = rd; }
+                    else { p = (rd + pr) % (ce - 1); q = (rd - pr + (ce - 1)) % (ce - 1); }
+                    if (p > q) { const int x = p; p = q; q = x; }
+                    if (q >= c) act = false;
+                }
                 double* wp = W + p * ldw; double* wq = W + q * ldw;
                 double a = 0.0, b = 0.0, g = 0.0;
-                for (int r = 0; r < n; ++r) { a = fma(wp[r], wp[r], a); b = fma(wq[r], wq[r], b); g = fma(wp[r], wq[r], g); }
-                if (a <= thr2 || b <= thr2) continue;
+                if (act)
+                    for (int r = sub; r < n; r += LP) { a = fma(wp[r], wp[r], a); b = fma(wq[r], wq[r], b); g = fma(wp[r], wq[r], g); }
+                a = ctx.quad_sum(a); b = ctx.quad_sum(b); g = ctx.quad_sum(g);
+                if (!act || a <= thr2 || b <= thr2) continue;
                 if (g == 0.0 || fabs(g) <= KB_EPS * sqrt(a * b)) continue;
                 rotated = 1;
                 const double zeta = (b - a) / (2.0 * g);
                 const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-                for (int r = 0; r < n; ++r) {
+                for (int r = sub; r < n; r += LP) {
                     const double x = wp[r], y = wq[r];
                     wp[r] = cs * x - sn * y; wq[r] = sn * x + cs * y;
                 }
                 double* vp = V + p * ldv; double* vq = V + q * ldv;
-                for (int r = 0; r < c; ++r) {
+                for (int r = sub; r < c; r += LP) {
                     const double x = vp[r], y = vq[r];
                     vp[r] = cs * x - sn * y; vq[r] = sn * x + cs * y;
                 }

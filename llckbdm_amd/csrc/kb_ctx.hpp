@@ -62,6 +62,13 @@ struct DevCtx {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
                                 __builtin_amdgcn_readlane(__double2loint(v), l));
     }
+    // sum over each group of four adjacent lanes (identical bits in the four); all lanes of the wavefront must be active
+    static constexpr int QUAD = 4;
+    __device__ __forceinline__ double quad_sum(double v) const {
+        v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+        v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+        return v;
+    }
     __device__ __forceinline__ double wave_sum(double v) const {
         v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
         v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
@@ -156,6 +163,8 @@ struct HostCtx {
     void lds_order() const {}
     char* scratch() const { return smem + KB_RED_BYTES; }
     int scratch_bytes() const { return smem_bytes - KB_RED_BYTES; }
+    static constexpr int QUAD = 1;
+    double quad_sum(double v) const { return v; }
     double wave_sum(double v) const { return v; }
     cd wave_sum(cd v) const { return v; }
     double wave_max(double v) const { return v; }

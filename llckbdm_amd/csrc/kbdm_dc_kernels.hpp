@@ -1,7 +1,8 @@
 // gfx950 kernels of the bidiagonal divide-and-conquer SVD (algorithm: kb_bdsdc.hpp; replaces the rotation replay of
 // the QR-iteration route for scipy.linalg.svd -> zgesdd -> dbdsdc, reference kbdm.py:166).
 //
-//   k_dc_leaf    one wavefront per (member, leaf): one-sided Jacobi of the <= 32-row leaf blocks
+//   k_dc_leaf    one workgroup of two wavefronts per (member, leaf): one-sided Jacobi of the <= 32-row leaf blocks, four
+//                lanes per pair of columns
 //   k_dc_setup   one workgroup per (member, node) of a depth: deflation, secular equation (one root per thread), Loewner
 //                z, the two coefficient matrices CU / CV
 //   k_dc_apply   all CUs: the node products  U = Ubasis CU,  V = Vbasis CV  as REAL FP64-MFMA tiles (the bases are block
@@ -82,7 +83,7 @@ __device__ __forceinline__ void mfma_rtile(FA Aop, FB Bop, FC Cstore, int k0, in
 
 __device__ __forceinline__ DcWs dc_item_ws(const KbItem& it, double* dcarena) { return dc_ws(dcarena + it.dc_off, it.m); }
 
-__global__ void __launch_bounds__(64) k_dc_leaf(const KbItem* __restrict__ items, const int* __restrict__ perm,
+__global__ void __launch_bounds__(128) k_dc_leaf(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                  double* varena, double* dcarena, int smem_bytes) {
     const KbItem it = items[perm[blockIdx.y]];
     const int m = it.m, L = dc_depth(m);

@@ -417,7 +417,7 @@ int launch_svd_dc(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     }
     {
         const int sm = KB_RED_BYTES + dc_leaf_scratch_bytes(KB_DC_LEAF);
-        hipLaunchKernelGGL(k_dc_leaf, dim3(1 << Lmax, ch.count), dim3(64), sm, ds, pl->d_items, perm, pl->d_varena, pl->d_dc, sm);
+        hipLaunchKernelGGL(k_dc_leaf, dim3(1 << Lmax, ch.count), dim3(128), sm, ds, pl->d_items, perm, pl->d_varena, pl->d_dc, sm);
     }
     for (int s = 0; s < Lmax; ++s) {
         const int sm = KB_RED_BYTES + dc_merge_scratch_bytes(nmax[s]);
