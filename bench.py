@@ -118,9 +118,17 @@ def cpu_baseline_serial(sig, ms, dwell, stride=5):
 
 
 def git_head():
+    """HEAD of the work tree, or - on a GPU box, whose snapshot has no .git - the head recorded when the library was built."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=10).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                           timeout=10).stdout.strip()
+        if h:
+            return h
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(os.path.dirname(_lib.LIB_PATH), ".build_head")) as f:
+            return f.read().strip() or None
     except Exception:
         return None
 
@@ -339,8 +347,15 @@ def main():
     if not multi:
         ns_ser = min(args.steps, 5)
         if nfl > 1:
-            ts = run_api_loop(eng, [works[0]], ns_ser, 1, resident=True)
-            serial = {"value": units * ns_ser / ts, "ms_per_step": 1e3 * ts / ns_ser, "steps": ns_ser, "ensembles_in_flight": 1}
+            ser_acc, ser_n = {}, [0]
+
+            def ser_done(h):
+                for name, v in h.plan.stage_ms().items():
+                    ser_acc[name] = ser_acc.get(name, 0.0) + v
+                ser_n[0] += 1
+            ts = run_api_loop(eng, [works[0]], ns_ser, 1, resident=True, on_done=ser_done)
+            serial = {"value": units * ns_ser / ts, "ms_per_step": 1e3 * ts / ns_ser, "steps": ns_ser, "ensembles_in_flight": 1,
+                      "stage_ms": {k: v / max(1, ser_n[0]) for k, v in ser_acc.items()}}
         if not args.no_extras:
             # SURVEY.md 8d's wording of the metric: host signals resident -> host line lists resident, through the same
             # public API, the same number of ensembles in flight
@@ -404,7 +419,10 @@ def main():
         traffic = traffic_src = None
         try:
             import glob
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            def newest_first(fn):          # r<round>_<milestone>_pmc_traffic.json: later round, then fin > end / last > mid > others
+                tag = os.path.basename(fn).split("_")
+                return (tag[0], {"fin": 3, "end": 2, "last": 2, "mid": 1}.get(tag[1], 0))
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=newest_first, reverse=True):
                 pmc = json.load(open(fn))["kernels"]
                 if kname in pmc:
                     traffic = pmc[kname].get("hbm_bytes_per_launch")
@@ -423,6 +441,13 @@ def main():
                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_ms": stage_ms[dom], "algorithmic_flops_per_launch": fl[dom],
                     "launch_members": n0}
+        if kname == "k_ab_iter":
+            roofline["launches_per_stage"] = "k_ab_leaf + 24 x levels k_ab_iter + k_ab_finish; `traffic` is ONE k_ab_iter launch"
+        if serial and serial.get("stage_ms", {}).get(dom, 0) > 0:
+            # the same stage with the GPU to itself (in the timed region four ensembles share the CUs, so a stage's HIP-event
+            # time there is its share of a busy chip, not its cost)
+            alone = fl[dom] / (serial["stage_ms"][dom] * 1e-3) / 1e12
+            roofline["one_ensemble_at_a_time"] = {"avg_ms": serial["stage_ms"][dom], "achieved": alone, "frac": alone / FP64_PEAK_TFLOPS}
         total_fl = sum(fl_all.values())
         out = {
             "metric": "KBDM solves/sec over m-range ensemble, N=2048 complex signal",

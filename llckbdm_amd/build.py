@@ -22,6 +22,7 @@ def _stale():
 def build_library(force=False, verbose=False):
     """Compile every HIP source for gfx950 into llckbdm_amd/libkbdm_hip.so."""
     if not force and not _stale():
+        _record_head()
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs (gfx90a+ register file).  Kernels whose accumulators are
@@ -32,7 +33,23 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
+    _record_head()
     return LIB
+
+
+def _record_head():
+    """Leave the git head of the tree the library was built from next to it (the GPU boxes get a snapshot without .git;
+    bench.py puts it into its JSON line)."""
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True,
+                               timeout=10).stdout.strip()
+        if head:
+            with open(os.path.join(os.path.dirname(LIB), ".build_head"), "w") as f:
+                f.write(head + ("+dirty" if dirty else "") + "\n")
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":
