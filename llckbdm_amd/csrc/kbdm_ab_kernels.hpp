@@ -21,12 +21,12 @@
 // (kb_smem, make_ctx, kb_d4 come from kbdm_kernels.hpp, which includes this file after kb_hqr2.hpp)
 
 constexpr int KB_AB_KC = 8;                     // k per staged chunk of the block product
+constexpr int KB_AB_TP = 33;                    // pitch (cd) of a wavefront's transposition area: 16 rows x 32 columns
 constexpr int KB_AB_PA = 48;                    // LDS pitch (doubles) of the H chunk rows: 2 * pitch = 32 mod 64 banks, so the two k rows
                                                 // of a half-wavefront's ds_read_b64 fall on disjoint banks
 
 struct AbLds {                                  // dynamic LDS of k_ab_iter
     double stage[4][2][2][KB_AB_KC][KB_AB_PA];  // [wavefront][H chunk | panel chunk][re|im][k][row / column]: private staging areas
-    kb::cd bf[KB_AB_BLK][2 * KB_AB_TILE];       // block rows x 128 columns: G, then the finished rows
     kb::cd ht[KB_AB_BLK][KB_AB_BLK + 1];        // the block's triangle of H (row k, column j), padded
     kb::cd inv[KB_AB_BLK];                      // 1 / H[k, k-1]
     kb::cd prow[2 * KB_AB_TILE];                // the finished row above the block (x_{k_hi}, y_{k_hi}); at the end rho, rho'
@@ -46,6 +46,20 @@ __device__ __forceinline__ double ab_lower_half(double v) {
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double((int)b[0], (int)a[0]);
 }
+// every lane gets the value of lane (lane | 32)
+__device__ __forceinline__ double ab_upper_half(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+// lanes 16-31 / 48-63 get the value of the lane 16 below, the others keep theirs (v_permlane16_swap)
+__device__ __forceinline__ double ab_row_below(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
 // LDS access through a 32-bit LDS address + byte offset (see the triangle of k_ab_iter)
 typedef double ab_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) ab_d2 ab_lds_d2;
@@ -60,8 +74,9 @@ __device__ __forceinline__ void ab_lds_st(unsigned base, int off, kb::cd v) {
 
 __device__ __forceinline__ kb::AbWs ab_item_ws(const kb::KbItem& it, double* dcarena) { return kb::ab_ws(dcarena + it.dc_off, it.l); }
 
-// column of the panel that holds root r's x (which = 0) / derivative (which = 1): a wavefront owns 32 roots with both
-__device__ __forceinline__ int ab_col(int r, int which) { return (r >> 5) * 64 + which * 32 + (r & 31); }
+// column of the panel that holds root r's x (which = 0) / derivative (which = 1): a wavefront owns 16 roots with both
+// (its 32 columns through the whole recurrence: block product, triangle, panel rows)
+__device__ __forceinline__ int ab_col(int r, int which) { return (r >> 4) * 32 + which * 16 + (r & 15); }
 
 // Sub-node (start, size) at depth d of a leaf of n rows that holds position j (the same halving as ab_node)
 __device__ __forceinline__ void ab_subnode(int n, int d, int j, int& sa, int& sn) {
@@ -287,7 +302,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     const int wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lk = lane >> 4;
     if (t < 2 * KB_AB_TILE) {                               // row n-1: x = 1, y = 0
-        const int c = t, which = (c >> 5) & 1;
+        const int c = t, which = (c >> 4) & 1;
         const cd v = which ? czero() : mk(1.0, 0.0);
         P[(size_t)(n - 1) * (2 * KB_AB_TILE) + c] = v;
         L.prow[c] = v;
@@ -434,75 +449,89 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             L.ht[r][j] = (r >= rmin && j >= rmin && j >= r - 1) ? htr[i] : czero();
         }
         if (t < KB_AB_BLK) L.inv[t] = (kb0s + t >= 1) ? ab_recip(hsub) : mk(-1.0, 0.0);      // k = 0: rho = the sum itself
-        // D element of lane (li, lk), register g: row = rb*16 + lk + 4 g, column = wave*32 + cb*16 + li
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    L.bf[rb * 16 + lk + 4 * g][wave * 32 + cb * 16 + li] = mk(acc_re[rb][cb][g], acc_im[rb][cb][g]);
         __syncthreads();
         lap(3);
-        // -- the triangle, two wavefronts (each 32 roots: lanes 0-31 x, lanes 32-63 the derivative): the running sums of
-        // all 32 rows of a column live in REGISTERS; as soon as p_{k-1} is known it is added into the rows above
-        // (right-looking), so a step is one dependent multiply plus independent updates, fully unrolled.
-        if (wave < 2 && !(dbg & 2)) {
-            const int c = wave * 64 + lane;                  // this lane's column
-            const double isyf = lane >= 32 ? 1.0 : 0.0;
-            const cd z = L.z[wave * 32 + (lane & 31)];
-            // LDS addresses as ONE laundered VGPR base + compile-time offsets (ds_read_b128 ... offset:imm): left to itself
-            // the compiler materialises each of the 500 wave-uniform addresses in an SGPR, spills them to VGPR lanes and pays
-            // v_readlane + v_mov per load
-            unsigned bfb = ab_lds_addr(&L.bf[0][c]), htb = ab_lds_addr(&L.ht[0][0]), ivb = ab_lds_addr(&L.inv[0]);
-            asm volatile("" : "+v"(bfb), "+v"(htb), "+v"(ivb));
-            cd rs[KB_AB_BLK];
+        // -- the triangle: every wavefront on its own 32 columns (16 roots: lanes 0-15 x, lanes 16-31 the derivative).  The two
+        // halves of the wavefront hold the same columns and share the rows of the block: half h keeps the running sums of the
+        // rows r = 2 i + h in REGISTERS.  Step r: the half that owns row r finishes it (one dependent multiply), both halves
+        // receive the result (v_permlane32_swap) and add it into their rows above (right-looking), fully unrolled.
+        {
+            const int h = lane >> 5, cl = lane & 31;
+            const int c = wave * 32 + cl;                    // this lane's column
+            const double isyf = (cl >= 16) ? 1.0 : 0.0;
+            const cd z = L.z[wave * 16 + (cl & 15)];
+            cd* Tw = reinterpret_cast<cd*>(&L.stage[wave][0][0][0][0]);          // the wavefront's staging area is free now
+            // LDS addresses as laundered VGPR bases + compile-time offsets (ds_read_b128 ... offset:imm): left to itself the
+            // compiler materialises every wave-uniform address in an SGPR, spills them to VGPR lanes and pays v_readlane + v_mov
+            unsigned tww = ab_lds_addr(Tw + lk * KB_AB_TP + li), twl = ab_lds_addr(Tw + h * KB_AB_TP + cl),
+                     htb = ab_lds_addr(&L.ht[h][0]), ivb = ab_lds_addr(&L.inv[0]);
+            asm volatile("" : "+v"(tww), "+v"(twl), "+v"(htb), "+v"(ivb));
+            // accumulators -> one column per lane, 16 rows at a time through the wavefront's area.  D element of lane (li, lk),
+            // register g: row = rb*16 + lk + 4 g, column = cb*16 + li.  (The DS operations of a wavefront execute in order.)
+            cd rs[KB_AB_BLK / 2];
 #pragma unroll
-            for (int r = 0; r < KB_AB_BLK; ++r) rs[r] = ab_lds_ld(bfb, r * (2 * KB_AB_TILE) * (int)sizeof(cd));
+            for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        ab_lds_st(tww, (4 * g * KB_AB_TP + cb * 16) * (int)sizeof(cd), mk(acc_re[rb][cb][g], acc_im[rb][cb][g]));
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rs[rb * 8 + j] = ab_lds_ld(twl, 2 * j * KB_AB_TP * (int)sizeof(cd));
+                __builtin_amdgcn_wave_barrier();
+            }
             cd pk = L.prow[c];                               // p_k of the step's row (own column)
+            if (!(dbg & 2)) {
             // (slots below rmin - rows k < 0 of the topmost block - run through the same code on zeros: no branches, one
             // basic block, so that the loads of the next steps' H columns are scheduled under the arithmetic of this one)
 #pragma unroll
             for (int r = KB_AB_BLK - 1; r >= 0; --r) {
-                cd hc[KB_AB_BLK];
+                constexpr int HALF = KB_AB_BLK / 2;
+                const int io = r >> 1, nup = (r + 1) >> 1;   // owner slot; slots updated (the upper half's surplus one at odd r is
+                                                             // its own slot io, overwritten below)
+                cd hc[HALF];
 #pragma unroll
-                for (int rp = 0; rp < KB_AB_BLK - 1; ++rp)
-                    if (rp < r) hc[rp] = ab_lds_ld(htb, (rp * (KB_AB_BLK + 1) + (r > 0 ? r - 1 : 0)) * (int)sizeof(cd));   // H[k', k-1], rows above
+                for (int i = 0; i < HALF; ++i)
+                    if (i < nup) hc[i] = ab_lds_ld(htb, (2 * i * (KB_AB_BLK + 1) + (r > 0 ? r - 1 : 0)) * (int)sizeof(cd));   // H[k', k-1], rows 2 i + h
                 const cd invr = ab_lds_ld(ivb, r * (int)sizeof(cd));
-                // the derivative lane needs x_k: the x lane of the same root is 32 lanes below
-                // (v_permlane32_swap: the upper half of the wavefront receives the lower half's value - a VALU move instead of
-                // a round trip through the LDS crossbar on the dependent chain of every step)
-                const double xkx = ab_lower_half(pk.x), xky = ab_lower_half(pk.y);
-                cd sv = rs[r] - z * pk;
+                // the derivative lane needs x_k: the x lane of the same root is 16 lanes below (v_permlane16_swap)
+                const double xkx = ab_row_below(pk.x), xky = ab_row_below(pk.y);
+                cd sv = rs[io] - z * pk;
                 sv.x = fma(-isyf, xkx, sv.x);
                 sv.y = fma(-isyf, xky, sv.y);
-                const cd res = -(sv * invr);                 // (row 0 of the matrix, rho itself: inv = -1)
-                rs[r] = res;
+                const cd mine = -(sv * invr);                // (row 0 of the matrix, rho itself: inv = -1)
+                const cd res = (r & 1) ? mk(ab_upper_half(mine.x), ab_upper_half(mine.y)) : mk(ab_lower_half(mine.x), ab_lower_half(mine.y));
                 pk = res;
 #pragma unroll
-                for (int rp = 0; rp < KB_AB_BLK - 1; ++rp)
-                    if (rp < r) cfma(rs[rp], hc[rp], res);                                  // ... times p_{k-1}
+                for (int i = 0; i < HALF; ++i)
+                    if (i < nup) cfma(rs[i], hc[i], res);                                   // ... times p_{k-1}
+                const bool own = h == (r & 1);
+                rs[io] = mk(own ? res.x : rs[io].x, own ? res.y : rs[io].y);
             }
-            if (kb0s <= 0) {                                 // the topmost block: slot rmin holds rho (x lanes) and rho' (y lanes)
+            }
+            if (kb0s <= 0) {                                 // the topmost block: row slot rmin holds rho (x lanes) and rho' (y lanes)
                 cd rho = rs[0];
 #pragma unroll
-                for (int r = 1; r < KB_AB_BLK; ++r)
-                    if (r == rmin) rho = rs[r];
-                L.prow[c] = rho;
+                for (int i = 1; i < KB_AB_BLK / 2; ++i)
+                    if (i == (rmin >> 1)) rho = rs[i];
+                if (h == (rmin & 1)) L.prow[c] = rho;
             } else {
-                // the finished rows kb0s-1 .. k_hi-1 straight from the registers (a row of 64 columns is 1 KB contiguous),
-                // the row above the next block, and the power-of-two rescaling of a column whose newest x has grown or
-                // shrunk a lot (decided on the x lane, shared with the derivative lane of the same root)
+                // the finished rows kb0s-1 .. k_hi-1 straight from the registers (half h: the rows 2 i + h; 32 columns are 512
+                // contiguous bytes), the row above the next block, and the power-of-two rescaling of a column whose newest x
+                // has grown or shrunk a lot (decided on the x lane of the lower half, shared with the derivative lane)
 #pragma unroll
-                for (int r = 0; r < KB_AB_BLK; ++r)
-                    if (!(dbg & 4)) P[(size_t)(kb0s + r - 1) * (2 * KB_AB_TILE) + c] = rs[r];
+                for (int i = 0; i < KB_AB_BLK / 2; ++i)
+                    if (!(dbg & 4)) P[(size_t)(kb0s + 2 * i + h - 1) * (2 * KB_AB_TILE) + c] = rs[i];
                 const double mx = fmax(fabs(rs[0].x), fabs(rs[0].y));
                 int e = 0;
                 if (mx > 0.0 && mx == mx && mx < 1.79769313486231570815e308) (void)frexp(mx, &e);
-                const double f = ab_lower_half((e > 60 || e < -60) ? ldexp(1.0, -e) : 1.0);
-                L.prow[c] = f * rs[0];
-                L.fac[c] = f;
-                if (f != 1.0) L.flags[1] = 1;
+                const double f = ab_row_below((e > 60 || e < -60) ? ldexp(1.0, -e) : 1.0);
+                if (h == 0) {
+                    L.prow[c] = f * rs[0];
+                    L.fac[c] = f;
+                    if (f != 1.0) L.flags[1] = 1;
+                }
             }
         }
         __syncthreads();
