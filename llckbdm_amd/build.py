@@ -46,7 +46,7 @@ def _record_head():
         dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True,
                                timeout=10).stdout.strip()
         if head:
-            with open(os.path.join(os.path.dirname(LIB), ".build_head"), "w") as f:
+            with open(os.path.join(os.path.dirname(LIB), "build_head.txt"), "w") as f:
                 f.write(head + ("+dirty" if dirty else "") + "\n")
     except Exception:
         pass
