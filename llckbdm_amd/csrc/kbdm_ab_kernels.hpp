@@ -301,6 +301,8 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     // ---- Hyman's recurrence, rows n-1 .. 0, blocks of 32 rows
     const int wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lk = lane >> 4;
+    const bool wact = wave * 16 < nr;                       // this wavefront's 16 roots: any of them live?
+    if (t < 2 * KB_AB_TILE) L.fac[t] = 1.0;
     if (t < 2 * KB_AB_TILE) {                               // row n-1: x = 1, y = 0
         const int c = t, which = (c >> 4) & 1;
         const cd v = which ? czero() : mk(1.0, 0.0);
@@ -404,6 +406,8 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
         lap(1);
+        if (wact) {                                          // (a wavefront whose 16 roots have all settled leaves its SIMD to the
+                                                             // other workgroup of the CU: no product, no triangle, no rows)
         fetch(0, S0{});
         fetch(1, S1{});
         stage(0, S0{});
@@ -441,6 +445,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             product();
         }
+        }
 #undef KB_AB_INTERLEAVE
         lap(2);
 #pragma unroll
@@ -455,7 +460,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         // halves of the wavefront hold the same columns and share the rows of the block: half h keeps the running sums of the
         // rows r = 2 i + h in REGISTERS.  Step r: the half that owns row r finishes it (one dependent multiply), both halves
         // receive the result (v_permlane32_swap) and add it into their rows above (right-looking), fully unrolled.
-        {
+        if (wact) {
             const int h = lane >> 5, cl = lane & 31;
             const int c = wave * 32 + cl;                    // this lane's column
             const double isyf = (cl >= 16) ? 1.0 : 0.0;
