@@ -97,6 +97,9 @@ struct kbdm_ctx {
     int split_gen = 32;   // workgroups per item and matrix in k_gen (columns of one matrix are independent)
     int split_invit = 8;  // workgroups per item in k_invit
     int invit_reg = 1;    // inverse iteration with register-resident vectors for l <= 512 (0: the LDS form)
+    int invit_wpb = 4;    // wavefronts per workgroup of k_invit_reg<2>, <4> (one per SIMD: the 256 VGPRs of a wavefront leave room for a
+                          // workgroup of another kernel - an MFMA-bound k_ab_iter tile beside this VALU-bound solve)
+    int invit_wpb8 = 4;   // ... of k_invit_reg<8>
     int team_hqr = 1;     // large members of lane 0: chase workgroup + helper workgroup (k_hqr_team)
     int team_min_l = 192; // smallest l that gets a team
     int hqr_wgs = -1;     // workgroups of the solo k_hqr launch (members are taken from a queue, largest first):
@@ -626,9 +629,11 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             lmaxc[c] = std::max(lmaxc[c], l);
         }
         auto nsplit = [](int lmax, int wpb) { return std::max(1, std::min((lmax + 2 * wpb - 1) / (2 * wpb), 64)); };
-        if (lmaxc[0]) hipLaunchKernelGGL(k_invit_reg<2>, dim3(clast[0] - cfirst[0] + 1, nsplit(lmaxc[0], 8)), dim3(512), 8 * 2 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[0], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 0);
-        if (lmaxc[1]) hipLaunchKernelGGL(k_invit_reg<4>, dim3(clast[1] - cfirst[1] + 1, nsplit(lmaxc[1], 8)), dim3(512), 8 * 4 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[1], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 128);
-        if (lmaxc[2]) hipLaunchKernelGGL(k_invit_reg<8>, dim3(clast[2] - cfirst[2] + 1, nsplit(lmaxc[2], 8)), dim3(512), 8 * 8 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[2], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 256);
+        // wavefronts per workgroup of the register-resident form (a solve does not depend on it: one eigenvalue per wavefront)
+        const int w2 = ctx->invit_wpb, w4 = ctx->invit_wpb, w8 = ctx->invit_wpb8;
+        if (lmaxc[0]) hipLaunchKernelGGL(k_invit_reg<2>, dim3(clast[0] - cfirst[0] + 1, nsplit(lmaxc[0], w2)), dim3(64 * w2), w2 * 2 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[0], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 0);
+        if (lmaxc[1]) hipLaunchKernelGGL(k_invit_reg<4>, dim3(clast[1] - cfirst[1] + 1, nsplit(lmaxc[1], w4)), dim3(64 * w4), w4 * 4 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[1], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 128);
+        if (lmaxc[2]) hipLaunchKernelGGL(k_invit_reg<8>, dim3(clast[2] - cfirst[2] + 1, nsplit(lmaxc[2], w8)), dim3(64 * w8), w8 * 8 * 64 * sizeof(cd), st, pl->d_items, perm + cfirst[2], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 256);
         if (lmaxc[3]) hipLaunchKernelGGL(k_invit_big<KB_INVIT_BIG_MAXC>, dim3(clast[3] - cfirst[3] + 1, nsplit(lmaxc[3], 4)), dim3(256), 0, st, pl->d_items, perm + cfirst[3], pl->d_arena, pl->d_varena, pl->d_mu, pl->d_status, 512);
         if (lmaxc[4]) {
             const int per4 = invit_scratch_bytes_per_wave(lmaxc[4]);
@@ -754,6 +759,8 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     c->split_invit = std::max(1, env_int("KBDM_SPLIT_INVIT", c->split_invit));
     c->team_hqr = env_int("KBDM_TEAM_HQR", c->team_hqr);
     c->invit_reg = env_int("KBDM_INVIT_REG", c->invit_reg);
+    c->invit_wpb = std::min(8, std::max(1, env_int("KBDM_INVIT_WPB", c->invit_wpb)));
+    c->invit_wpb8 = std::min(8, std::max(1, env_int("KBDM_INVIT_WPB8", c->invit_wpb8)));
     c->team_min_l = env_int("KBDM_TEAM_MIN_L", c->team_min_l);
     c->hqr_wgs = std::max(-1, env_int("KBDM_HQR_WGS", c->hqr_wgs));
     c->team_max = std::min(120, std::max(1, env_int("KBDM_TEAM_MAX", c->team_max)));
