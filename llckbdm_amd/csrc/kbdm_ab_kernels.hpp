@@ -488,10 +488,12 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
             }
             cd pk = L.prow[c];                               // p_k of the step's row (own column)
             if (!(dbg & 2)) {
-            // (slots below rmin - rows k < 0 of the topmost block - run through the same code on zeros: no branches, one
-            // basic block, so that the loads of the next steps' H columns are scheduled under the arithmetic of this one)
+            // (slots below rmin - rows k < 0 of the topmost block - run through the same code on zeros: basic blocks of eight
+            // steps, so that the loads of the next steps' H columns are scheduled under the arithmetic of this one; the topmost
+            // block leaves after the group that holds its last row)
 #pragma unroll
             for (int r = KB_AB_BLK - 1; r >= 0; --r) {
+                if ((r & 7) == 7 && r < KB_AB_BLK - 1 && rmin > r) break;
                 constexpr int HALF = KB_AB_BLK / 2;
                 const int io = r >> 1, nup = (r + 1) >> 1;   // owner slot; slots updated (the upper half's surplus one at odd r is
                                                              // its own slot io, overwritten below)
