@@ -116,6 +116,8 @@ int kbdm_plan_lane0_members(const kbdm_plan* plan);
 /* Members of the last run whose eigenvalues came from the QR iteration because the divide-and-conquer Ehrlich-Aberth
  * path declined them (negligible subdiagonal, a root that did not settle, power-sum check); waits for the plan. */
 int kbdm_plan_eig_fallbacks(kbdm_plan* plan);
+/* the same count for the last kbdm_eig_batch call on this context (the stage entry point owns its plan); -1: no context */
+int kbdm_ctx_last_eig_fallbacks(kbdm_ctx* ctx);
 /* Diagnostics of that path: out[step * 24 + iteration] = root tiles (64 roots each) that were still iterating in that
  * launch, summed over the runs since the last call (n <= 16 * 24 entries); waits for the plan. */
 int kbdm_plan_ab_stats(kbdm_plan* plan, int32_t* out, int n);

@@ -53,6 +53,7 @@ SYMBOLS = {
     "kbdm_stage_name": (c_char_p, [c_int]),
     "kbdm_plan_lane0_members": (c_int, [_P]),
     "kbdm_plan_eig_fallbacks": (c_int, [_P]),
+    "kbdm_ctx_last_eig_fallbacks": (c_int, [_P]),
     "kbdm_plan_ab_stats": (c_int, [_P, _P, c_int]),
     "kbdm_rmse_batch": (c_int, [_P, _P, c_int, c_double, _P, _P, c_int, _P]),
     "kbdm_silhouette_samples": (c_int, [_P, _P, c_int, c_int, _P, _P]),

@@ -96,6 +96,7 @@ struct kbdm_ctx {
     int nt_invit = 1024;
     int split_gen = 32;   // workgroups per item and matrix in k_gen (columns of one matrix are independent)
     int split_invit = 8;  // workgroups per item in k_invit
+    int last_eig_fallbacks = 0;   // members the Aberth path handed to the QR iteration in the last kbdm_eig_batch call
     int invit_reg = 1;    // inverse iteration with register-resident vectors for l <= 512 (0: the LDS form)
     int invit_wpb = 4;    // wavefronts per workgroup of k_invit_reg<2>, <4> (one per SIMD: the 256 VGPRs of a wavefront leave room for a
                           // workgroup of another kernel - an MFMA-bound k_ab_iter tile beside this VALU-bound solve)
@@ -1377,12 +1378,15 @@ int kbdm_eig_batch(kbdm_ctx* ctx, const double* W, int B, const int32_t* n, doub
         if (P) HIPTRY(hipMemcpy(P, d_dense, sizeof(cd) * tot, hipMemcpyDeviceToHost));
         if (mu) HIPTRY(hipMemcpy(mu, pl->d_mu, sizeof(cd) * pl->total_lines, hipMemcpyDeviceToHost));
         if (status) HIPTRY(hipMemcpy(status, pl->d_status, sizeof(int) * B, hipMemcpyDeviceToHost));
+        ctx->last_eig_fallbacks = kbdm_plan_eig_fallbacks(pl);
         HIPTRY(hipGetLastError());
     } while (0);
     hipFree(d_dense);
     kbdm_plan_destroy(pl);
     return r;
 }
+
+int kbdm_ctx_last_eig_fallbacks(kbdm_ctx* ctx) { return ctx ? ctx->last_eig_fallbacks : -1; }
 
 // ---------------------------------------------------------------- rows next to the hot path
 int kbdm_rmse_batch(kbdm_ctx* ctx, const double* data, int N, double dwell, const double* lines,

@@ -509,6 +509,10 @@ class Engine:
             so += ni
         return out, status
 
+    def last_eig_fallbacks(self):
+        """Members the Ehrlich-Aberth path handed to the QR iteration in the last `eig` call of this engine."""
+        return int(self.lib.kbdm_ctx_last_eig_fallbacks(self.ctx))
+
     def close(self):
         if self.ctx is not None:
             self.clear_plan_cache()

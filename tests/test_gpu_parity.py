@@ -84,6 +84,26 @@ def test_eig_stage(eng):
         assert np.all(np.abs(P).max(axis=0) > 0)
 
 
+def test_eig_stage_rescales_the_recurrence(eng):
+    """Upper Hessenberg matrices whose subdiagonals are all small (the solutions of Hyman's recurrence grow by 16 per row:
+    2^128 per block of 32 rows, 2^1000 over the matrix) or all large (they shrink as fast): the Aberth path has to rescale
+    its columns at block ends, in both directions, and must not hand these members to the QR iteration."""
+    rng = np.random.default_rng(5)
+    mats = []
+    for n, sub in ((200, 1.0 / 16), (300, 1.0 / 16), (260, 16.0), (97, 1.0 / 64)):
+        W = np.triu(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        W[np.arange(1, n), np.arange(n - 1)] = sub * np.exp(2j * np.pi * rng.random(n - 1))
+        mats.append(W)
+    out, status = eng.eig(mats)
+    assert not (status & 3).any()
+    assert eng.last_eig_fallbacks() == 0
+    for W, (mu, P) in zip(mats, out):
+        ref = np.linalg.eigvals(W)
+        nrm = np.abs(W).sum(axis=1).max()
+        d = np.abs(mu[:, None] - ref[None, :])
+        assert d.min(axis=1).max() < 1e-10 * nrm and d.min(axis=0).max() < 1e-10 * nrm
+
+
 def test_eig_team_and_solo_paths_agree_bitwise(monkeypatch):
     """k_hqr_team (chase workgroup + helper workgroup on two CUs, hand-off through HBM) applies
     exactly the arithmetic of the one-workgroup k_hqr, element by element: any stale or torn hand-off
