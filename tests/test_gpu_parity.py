@@ -104,6 +104,29 @@ def test_eig_stage_rescales_the_recurrence(eng):
         assert d.min(axis=1).max() < 1e-10 * nrm and d.min(axis=0).max() < 1e-10 * nrm
 
 
+def test_eig_stage_members_the_aberth_path_declines_go_to_the_qr_iteration(eng):
+    """A matrix that splits (an exactly zero or negligible subdiagonal: Hyman's recurrence divides by it) is handed to the
+    QR iteration, member by member: its neighbours in the batch stay on the Aberth path, every member comes back right."""
+    rng = np.random.default_rng(6)
+
+    def hess(n):
+        return np.triu(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)), -1)
+    a = hess(200)
+    b = hess(180); b[90, 89] = 0.0
+    c = hess(150); c[40, 39] = 1e-300
+    d = hess(97)
+    mats = [a, b, c, d]
+    out, status = eng.eig(mats)
+    assert not (status & 3).any()
+    assert eng.last_eig_fallbacks() == 2
+    for W, (mu, P) in zip(mats, out):
+        ref = np.linalg.eigvals(W)
+        nrm = np.abs(W).sum(axis=1).max()
+        dist = np.abs(mu[:, None] - ref[None, :])
+        assert dist.min(axis=1).max() < 1e-11 * nrm and dist.min(axis=0).max() < 1e-11 * nrm
+        assert np.abs(W @ P - P * mu[None, :]).max() < 1e-12 * nrm * W.shape[0]
+
+
 def test_eig_team_and_solo_paths_agree_bitwise(monkeypatch):
     """k_hqr_team (chase workgroup + helper workgroup on two CUs, hand-off through HBM) applies
     exactly the arithmetic of the one-workgroup k_hqr, element by element: any stale or torn hand-off

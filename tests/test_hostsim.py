@@ -55,6 +55,32 @@ def test_svd_random_and_degenerate(hs):
         assert np.abs(s - np.linalg.svd(A, compute_uv=False)).max() < 1e-13 * scale * m
 
 
+def test_householder_generator_survives_underflow_and_overflow_of_the_squares(hs):
+    """zlarfg rescales when the squares of a vector's entries underflow or overflow; so does `larfg`: matrices scaled by
+    1e-200 / 1e+200 (bidiagonalisation) and a Hessenberg matrix with subdiagonals between 1e-160 and denormal (the
+    Hessenberg reduction in front of the QR iteration; found as NaN eigenvalues of a member with a 1e-300 subdiagonal)."""
+    rng = np.random.default_rng(12)
+    for scale in (1e-200, 1e200):
+        m = 20
+        A = (rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))) * scale
+        Af = np.asfortranarray(A)
+        L, R, s = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F"), np.zeros(m)
+        assert hs.hs_svd(Af.ctypes.data_as(P), m, L.ctypes.data_as(P), s.ctypes.data_as(P), R.ctypes.data_as(P)) == 0
+        ref = np.linalg.svd(A / scale, compute_uv=False)
+        assert np.isfinite(s).all() and np.abs(s / scale - ref).max() < 1e-13 * m * ref[0]
+        assert np.abs((L * (s / scale)) @ R.conj().T - A / scale).max() < 1e-12 * m
+    hs.hs_eigvals2.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, ctypes.c_int]
+    for val in (1e-160, 1e-200, 1e-300, 1e-310):
+        n = 60
+        W = np.triu(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)), -1)
+        W[25, 24] = val
+        Wf = np.asfortranarray(W)
+        mu, st = np.zeros(n, complex), np.zeros(16, np.int64)
+        assert hs.hs_eigvals2(Wf.ctypes.data_as(P), n, 8, 56, 0, mu.ctypes.data_as(P), st.ctypes.data_as(P), 0) == 0
+        ref = np.linalg.eigvals(W)
+        assert np.abs(mu[:, None] - ref[None, :]).min(axis=1).max() < 1e-11 * n
+
+
 def test_eig_random(hs):
     rng = np.random.default_rng(2)
     for n in (1, 2, 3, 16, 40, 96, 130):     # 96 and 130: one and two blocked Hessenberg panels (+ k_hess_z's reference form)
