@@ -84,6 +84,27 @@ def test_eig_stage(eng):
         assert np.all(np.abs(P).max(axis=0) > 0)
 
 
+def test_signal_scale_goes_into_the_amplitudes_only(eng):
+    """The path is homogeneous in the signal: a signal times 1e30 / 1e120 gives the same T2, F, PH and the amplitudes times the
+    factor (the squares of its Hankel entries overflow FP64 for 1e160: out of range for the reference too); times 1e-30 every
+    amplitude falls under the filter's absolute threshold (sampling.py:75-97) exactly as in the reference: no line kept."""
+    from llckbdm_amd.kbdm import kbdm
+    from oracle import kbdm_oracle as O
+    sig = O.make_noisy(O.brain_sim_signal(2048), 1e-3, 3)
+    base, _ = kbdm(sig, DWELL, m=150, p=1, l=None, q=0, engine=eng)
+    kb = canonical(base[keep_mask(base)])
+    for f in (1e30, 1e120):
+        ll, info = kbdm(sig * f, DWELL, m=150, p=1, l=None, q=0, engine=eng)
+        k = canonical(ll[keep_mask(ll)])
+        assert k.shape == kb.shape
+        assert np.abs(k[:, 0] / f - kb[:, 0]).max() <= 1e-9 * np.abs(kb[:, 0]).max()
+        assert_lines_close(np.column_stack([kb[:, 0], k[:, 1:]]), kb, rel=1e-7, phase_abs=1e-7, what=f"scale {f}")
+        assert np.abs(info.singular_values / f - _.singular_values).max() <= 1e-12 * _.singular_values[0]
+    ll, info = kbdm(sig * 1e-30, DWELL, m=150, p=1, l=None, q=0, engine=eng)
+    assert np.isfinite(ll).all() and not keep_mask(ll).any()
+    assert np.abs(np.sort(ll[:, 0]) / 1e-30 - np.sort(base[:, 0])).max() <= 1e-6 * np.abs(base[:, 0]).max()
+
+
 def test_eig_stage_rescales_the_recurrence(eng):
     """Upper Hessenberg matrices whose subdiagonals are all small (the solutions of Hyman's recurrence grow by 16 per row:
     2^128 per block of 32 rows, 2^1000 over the matrix) or all large (they shrink as fast): the Aberth path has to rescale
