@@ -1065,6 +1065,20 @@ KB_HD void hqr2_eigvals(const C& ctx, int n, cd* H, int ld, cd* w, int* info, in
         return;
     }
     ctx.sync();
+    {   // a matrix that is not finite (an exactly singular U^{p-1}: Dsqi = inf) would only burn its 30 n sweeps: fail at once
+        int nonfinite = 0;
+        for (int k = tid; k < n; k += nt) {
+            const cd a = HH(k, k), b = (k > 0) ? HH(k, k - 1) : czero();
+            if (!((a.x - a.x == 0.0) && (a.y - a.y == 0.0) && (b.x - b.x == 0.0) && (b.y - b.y == 0.0))) nonfinite = 1;
+        }
+        nonfinite = ctx.block_max(nonfinite);
+        if (nonfinite) {
+            if (tid == 0) *info = 1;
+            ctx.sync();
+            if (team) team_signal(ctx, &team->ctl->done, 1u);
+            return;
+        }
+    }
     const int itmax = 30 * (n > 10 ? n : 10);
     int kdefl = 0;
     int i = n - 1;

@@ -76,6 +76,12 @@ def checked(engine, res, signals, sig_idx, m, l, p, q, dwell, what="KBDM"):
             res.sv[res.sv_off[i]:res.sv_off[i + 1]] = again.singular_values(k)
             res.status[i] = again.status[k]
         still = np.nonzero(res.status & hard)[0]
+        if len(still) and q == 0:
+            # an exactly singular U^{p-1} (a zero singular value among the l retained ones): the reference inverts
+            # sqrt(diag(s)) there (kbdm.py:168-186) and numpy raises "Singular matrix"
+            sing = [int(i) for i in still if not np.all(res.sv[res.sv_off[i]:res.sv_off[i] + int(l[i])] > 0)]
+            if sing:
+                raise np.linalg.LinAlgError("Singular matrix")
         if len(still):
             svd = [int(i) for i in still if res.status[i] & _lib.STAT_SVD_NOCONV]
             eig = [int(i) for i in still if res.status[i] & _lib.STAT_EIG_NOCONV]

@@ -141,3 +141,28 @@ def test_plan_cache_is_bounded_by_bytes():
         assert len(e._slots[0].plans) == 2
     finally:
         e.close()
+
+
+def test_degenerate_signals_behave_as_in_the_reference(eng):
+    """An all-zero or constant signal makes U^{p-1} exactly singular: the reference inverts sqrt(diag(s)) (kbdm.py:168-186)
+    and numpy raises LinAlgError("Singular matrix") - for the constant signal only where LAPACK happens to return an exact
+    zero (m = 12 here, not m = 64); this path raises it for every such input.  One or two exponentials (rank 1 / 2 Hankel
+    matrices whose other singular values are rounding noise) come back with exactly those lines, as the oracle's."""
+    from llckbdm_amd.kbdm import kbdm
+    from oracle import kbdm_oracle as O
+    from tests.helpers import canonical, keep_mask, assert_lines_close
+    N = 256
+    n = np.arange(N)
+    for sig in (np.zeros(N, complex), np.ones(N, complex)):
+        for m in (12, 64):
+            with pytest.raises(np.linalg.LinAlgError, match="Singular matrix"):
+                kbdm(sig, 5e-4, m=m, p=1, l=None, q=0, engine=eng)
+    one = 2.0 * np.exp((-0.01 + 0.3j) * n)
+    two = one + 0.5 * np.exp((-0.02 - 0.7j) * n + 0.4j)
+    for sig, nk in ((one, 1), (two, 2)):
+        for m in (12, 64):
+            ll, info = kbdm(sig, 5e-4, m=m, p=1, l=None, q=0, engine=eng)
+            want, _ = O.kbdm(sig, 5e-4, m=m, p=1, l=None, q=0)
+            k, w = canonical(ll[keep_mask(ll)]), canonical(want[keep_mask(want)])
+            assert len(k) == nk == len(w)
+            assert_lines_close(k, w, rel=1e-8, phase_abs=1e-8, what=f"{nk} exponential(s), m = {m}")
