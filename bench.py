@@ -127,7 +127,7 @@ def git_head():
     except Exception:
         pass
     try:
-        with open(os.path.join(os.path.dirname(_lib.LIB_PATH), "build_head.txt")) as f:
+        with open(os.path.join(ROOT, "llckbdm_amd", "build_head.txt")) as f:
             return f.read().strip() or None
     except Exception:
         return None
