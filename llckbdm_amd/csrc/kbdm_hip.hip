@@ -189,7 +189,7 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_iter), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_tfac), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_apply), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_apply), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_APPLY_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -364,7 +364,7 @@ int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream
         for (int s = 0; s < nblk; ++s) {
             // a member's trailing matrix at step s has at most (s + 1) 64 + 2 rows (its last block is the partial one)
             const int span = std::min(nmax, (s + 2) * KB_WYB);
-            hipLaunchKernelGGL(k_wy_apply, dim3((span + 63) / 64, ch.count, nmat), dim3(256), KB_WY_LDS, gst, pl->d_items, perm,
+            hipLaunchKernelGGL(k_wy_apply, dim3((span + 63) / 64, ch.count, nmat), dim3(256), KB_WY_APPLY_LDS, gst, pl->d_items, perm,
                                pl->d_arena, pl->d_varena, mode, s);
         }
     }

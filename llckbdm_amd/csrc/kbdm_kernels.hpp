@@ -377,6 +377,9 @@ __global__ void __launch_bounds__(256) k_wy_init(const KbItem* __restrict__ item
 }
 
 constexpr int KB_WY_LDS = (int)(2 * sizeof(kb_tu_stage) + KB_WYB * (KB_WYB + 1) * sizeof(cd) + KB_WYB * sizeof(cd));
+// k_wy_apply: Z / Y without padding, row i rotated by i instead (the same bank spread): 84 KB - a tile of k_ab_iter (75 KB)
+// fits beside it on the CU
+constexpr int KB_WY_APPLY_LDS = (int)(2 * sizeof(kb_tu_stage) + KB_WYB * KB_WYB * sizeof(cd));
 
 __global__ void __launch_bounds__(256) k_wy_tfac(const KbItem* __restrict__ items, const int* __restrict__ perm, cd* arena,
                                                   double* varena, int mode) {
@@ -435,23 +438,24 @@ __global__ void __launch_bounds__(256) k_wy_apply(const KbItem* __restrict__ ite
     if (c0 >= ncols) return;
     extern __shared__ __align__(16) unsigned char wy_smem[];
     kb_tu_stage* s_op = reinterpret_cast<kb_tu_stage*>(wy_smem);
-    cd (*Zs)[KB_WYB + 1] = reinterpret_cast<cd (*)[KB_WYB + 1]>(wy_smem + 2 * sizeof(kb_tu_stage));     // [column][reflector]
+    cd (*Zr)[KB_WYB] = reinterpret_cast<cd (*)[KB_WYB]>(wy_smem + 2 * sizeof(kb_tu_stage));     // [column][reflector + column mod 64]
+#define Zs_(i_, j_) Zr[(i_)][((j_) + (i_)) & (KB_WYB - 1)]
     const cd* Tg = g.Tws + (size_t)blk * (KB_WYB * KB_WYB);
     // Zs[c][j] = sum_r C[r][c] conj(V[r][j]) = (V^H C)[j][c]
     mfma_tile_ks<true, true>(
         s_op,
         [&](int i, int kk) -> cd { return (kk < nrows && c0 + i < ncols) ? g.Out[(p0 + kk) + (size_t)(p0 + c0 + i) * g.n] : czero(); },
         [&](int j, int kk) -> cd { return kk < nrows ? wy_v(g, p0 + kk, kb + j) : czero(); },
-        [&](int i, int j) -> cd* { return &Zs[i][j]; },
+        [&](int i, int j) -> cd* { return &Zs_(i, j); },
         (nrows + KB_TU_KC - 1) / KB_TU_KC);
     __syncthreads();
     // Yc[c][j] = conj( sum_k T[j][k] Z[k][c] ) = sum_k conj(Zs[c][k]) conj(T[j][k]); written over Zs (the product's operand
     // reads end at the barrier that closes its last chunk)
     mfma_tile_ks<true, false>(
         s_op,
-        [&](int i, int k) -> cd { return conj(Zs[i][k]); },
+        [&](int i, int k) -> cd { return conj(Zs_(i, k)); },
         [&](int j, int k) -> cd { return Tg[j * KB_WYB + k]; },
-        [&](int i, int j) -> cd* { return &Zs[i][j]; },
+        [&](int i, int j) -> cd* { return &Zs_(i, j); },
         KB_WYB / KB_TU_KC);
     __syncthreads();
     // C[r][c] -= sum_j V[r][j] Y[j][c],  Y[j][c] = conj(Yc[c][j])
@@ -459,13 +463,14 @@ __global__ void __launch_bounds__(256) k_wy_apply(const KbItem* __restrict__ ite
         mfma_tile_ks<false, false>(
             s_op,
             [&](int i, int j) -> cd { return wy_v(g, p0 + r0 + i, kb + j); },
-            [&](int i, int j) -> cd { return Zs[i][j]; },
+            [&](int i, int j) -> cd { return Zs_(i, j); },
             [&](int i, int jx) -> cd* {
                 const int r = r0 + i, c = c0 + jx;
                 return (r < nrows && c < ncols) ? &g.Out[(p0 + r) + (size_t)(p0 + c) * g.n] : nullptr;
             },
             KB_WYB / KB_TU_KC);
 }
+#undef Zs_
 
 #include "kbdm_dc_kernels.hpp"
 
