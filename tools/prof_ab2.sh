@@ -1,6 +1,7 @@
 #!/bin/bash
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-for dbg in 0 1 2 3; do
+# KBDM_AB_DBG: 2 no triangle, 4 no panel row stores (results are wrong then - timing only); tools/ab_phases.py (8) gives the split directly
+for dbg in 0 2 4 6; do
 rm -rf $OUT/prof_ab
 KBDM_AB_DBG=$dbg KBDM_EIG_AB=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ab -- python3 $ROOT/tools/check_ab.py C1 > $OUT/prof_ab.log 2>&1
 python3 - $dbg <<'PY'
