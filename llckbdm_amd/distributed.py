@@ -13,7 +13,7 @@ import warnings
 import numpy as np
 
 from . import _lib
-from .kbdm import KbdmInfo, _resolve_m_l
+from .kbdm import KbdmInfo, _check_finite, _resolve_m_l
 
 
 def shard_items(costs, world_size):
@@ -186,6 +186,11 @@ def sample_kbdm_signals_sharded(signals, dwell, sig_idx, m_list, p=1, l=None, q=
         ls.append(ll)
     ms, ls = np.asarray(ms, dtype=np.int32), np.asarray(ls, dtype=np.int32)
     sig_idx = np.asarray(sig_idx, dtype=np.int32)
+    if len(ms):                                  # ValueError for NaN / Inf samples on EVERY rank, before anything is dealt
+        wid = np.zeros(signals.shape[0], dtype=np.int64)
+        np.maximum.at(wid, sig_idx, ms.astype(np.int64))
+        for k in np.nonzero(wid)[0]:
+            _check_finite(signals[k], int(wid[k]), p)
     world, rank = comm.world, comm.rank
     parts = shard_items(ms.astype(np.float64) ** 3, world)
     sizes = np.array([packed_bytes(ls[idx].sum(), ms[idx].sum(), len(idx)) for idx in parts], dtype=np.int64)

@@ -36,6 +36,14 @@ def _resolve_m_l(data_size, m, p, l):
     return int(m), int(l)
 
 
+def _check_finite(data, m, p):
+    """scipy.linalg.svd / eig (kbdm.py:166,192) are called with check_finite=True: a NaN or Inf among the samples that
+    enter U^{p-1} or U^p - data[p-1 : 2 m + p - 1] - raises ValueError there, with this message, before any result exists."""
+    lo, hi = max(int(p) - 1, 0), 2 * int(m) + int(p) - 1
+    if not np.isfinite(np.asarray(data).reshape(-1)[lo:hi]).all():
+        raise ValueError("array must not contain infs or NaNs")
+
+
 def kbdm(data, dwell, m=None, p=1, l=None, q=0, engine=None):
     """One KBDM solve on the GPU.  Reference: kbdm.py:19-92.
 
@@ -43,6 +51,7 @@ def kbdm(data, dwell, m=None, p=1, l=None, q=0, engine=None):
     """
     data = np.asarray(data)
     m, l = _resolve_m_l(data.size, m, p, l)
+    _check_finite(data, m, p)
     if q > 0:
         logger.debug('Using Tikhonov Regularization with q=%f', q)      # reference kbdm.py:180
     eng = engine or default_engine()

@@ -5,7 +5,7 @@ import logging
 import numpy as np
 
 from .engine import default_engine
-from .kbdm import KbdmInfo, _resolve_m_l
+from .kbdm import KbdmInfo, _check_finite, _resolve_m_l
 
 logger = logging.getLogger(__name__)
 
@@ -28,6 +28,7 @@ def sample_kbdm(data, dwell, m_range, p, l, q=0, filter_invalid_features=True, e
         ls.append(ll)
     if not ms:
         return [], []
+    _check_finite(data, max(ms), p)          # the first member whose window holds a NaN / Inf raises in the reference's loop
     eng = engine or default_engine()
     # check=True: a member the solver flags as not converged is retried once, then numpy.linalg.LinAlgError is raised,
     # as scipy.linalg.svd / eig would inside the reference's kbdm() (kbdm.py:166,192)
@@ -60,8 +61,14 @@ def sample_kbdm_signals(signals, dwell, sig_idx, m_list, p=1, l=None, q=0, filte
             kbdm_logger.debug('Using Tikhonov Regularization with q=%f', q)
         ms.append(mm)
         ls.append(ll)
+    sig_idx = np.asarray(sig_idx, dtype=np.int32)
+    if len(ms):                                  # (per signal: the widest window any of its members uses)
+        wid = np.zeros(signals.shape[0], dtype=np.int64)
+        np.maximum.at(wid, sig_idx, np.asarray(ms, dtype=np.int64))
+        for k in np.nonzero(wid)[0]:
+            _check_finite(signals[k], int(wid[k]), p)
     eng = engine or default_engine()
-    res = _solve_in_flight(eng, signals, np.asarray(sig_idx, dtype=np.int32), ms, ls, p, q, dwell)
+    res = _solve_in_flight(eng, signals, sig_idx, ms, ls, p, q, dwell)
     line_lists, infos, index = [], [], []
     for i, (m, ll) in enumerate(zip(ms, ls)):
         line_list = res.line_list(i)

@@ -56,3 +56,36 @@ def test_sig_gen_matches_oracle(golden):
     # lorentzian of a peak == analytic FT of its FID (reference test_sig_gen checks the same property)
     p = (1.0, 0.05, 100.0, 0.3)
     assert sig_gen.lorentzian_peak(np.array([100.0]), *p)[0] == pytest.approx(0.05 * np.exp(0.3j))
+
+
+def test_non_finite_samples_raise_valueerror_as_scipy_does():
+    """scipy.linalg.svd / eig run with check_finite=True in the reference (kbdm.py:166,192): a NaN / Inf among the samples a
+    member uses raises ValueError("array must not contain infs or NaNs"); one beyond its window goes unnoticed.  Checked on
+    the host, before any GPU work (a fake engine records that nothing was submitted)."""
+    import numpy as np
+    import pytest
+    from llckbdm_amd.kbdm import kbdm
+    from llckbdm_amd.sampling import sample_kbdm, sample_kbdm_signals
+    from tests.fake_engine import OracleEngine
+
+    class FakeEngine(OracleEngine):
+        calls = 0
+
+        def solve(self, *a, **k):
+            self.calls += 1
+            return super().solve(*a, **k)
+    sig = np.exp((-0.01 + 0.3j) * np.arange(256)) + 1e-3 * np.random.default_rng(0).standard_normal(256)
+    for idx, val in ((5, np.nan), (30, np.inf)):
+        bad = sig.copy(); bad[idx] = val
+        eng = FakeEngine()
+        with pytest.raises(ValueError, match="array must not contain infs or NaNs"):
+            kbdm(bad, 5e-4, m=16, p=1, engine=eng)
+        with pytest.raises(ValueError, match="array must not contain infs or NaNs"):
+            sample_kbdm(bad, 5e-4, range(8, 17, 2), p=1, l=None, engine=eng)
+        with pytest.raises(ValueError, match="array must not contain infs or NaNs"):
+            sample_kbdm_signals(np.stack([sig, bad]), 5e-4, [0, 1, 1], [16, 12, 16], engine=eng)
+        assert eng.calls == 0
+    far = sig.copy(); far[200] = np.nan                       # outside data[0 : 2 m + p - 1] = data[0:32]
+    eng = FakeEngine()
+    kbdm(far, 5e-4, m=16, p=1, engine=eng)
+    assert eng.calls == 1
