@@ -449,6 +449,9 @@ def main():
             alone = fl[dom] / (serial["stage_ms"][dom] * 1e-3) / 1e12
             roofline["one_ensemble_at_a_time"] = {"avg_ms": serial["stage_ms"][dom], "achieved": alone, "frac": alone / FP64_PEAK_TFLOPS}
         total_fl = sum(fl_all.values())
+        pipe = total_fl * args.steps * (1 if args.sharded else world) / elapsed / 1e12
+        roofline["whole_pipeline"] = {"achieved": pipe, "frac": pipe / (FP64_PEAK_TFLOPS * world), "unit": "TFLOP/s",
+                                      "note": "algorithmic flops of every stage of every member (SURVEY.md 8d) over the timed region"}
         out = {
             "metric": "KBDM solves/sec over m-range ensemble, N=2048 complex signal",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
