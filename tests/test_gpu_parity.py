@@ -84,6 +84,30 @@ def test_eig_stage(eng):
         assert np.all(np.abs(P).max(axis=0) > 0)
 
 
+def test_tiny_members_and_pure_noise(eng):
+    """m = 1 .. 9 with p = 1 .. 3 and l <= m (two exponentials + noise, N = 64), and a signal that is nothing but noise:
+    every line with a visible amplitude against the oracle."""
+    from llckbdm_amd.kbdm import kbdm
+    rng = np.random.default_rng(1)
+    n = np.arange(64)
+    sig = 2.0 * np.exp((-0.01 + 0.3j) * n) + 0.7 * np.exp((-0.03 - 1.1j) * n) + 1e-3 * (rng.standard_normal(64) + 1j * rng.standard_normal(64))
+    for m in (1, 2, 3, 4, 5, 7, 9):
+        for p in (1, 2, 3):
+            for l in sorted({m, max(1, m - 1), max(1, m // 2)}):
+                ll, info = kbdm(sig, DWELL, m=m, p=p, l=l, engine=eng)
+                want, _ = O.kbdm(sig, DWELL, m=m, p=p, l=l)
+                a, b = canonical(ll), canonical(want)
+                assert a.shape == b.shape == (l, 4)
+                strong = np.abs(b[:, 0]) > 1e-3
+                assert_lines_close(a[strong], b[strong], rel=1e-8, phase_abs=1e-8, what=f"m={m} p={p} l={l}")
+    noise = rng.standard_normal(512) + 1j * rng.standard_normal(512)
+    ll, info = kbdm(noise, DWELL, m=128, p=1, engine=eng)
+    want, _ = O.kbdm(noise, DWELL, m=128, p=1)
+    a, b = canonical(ll[keep_mask(ll)]), canonical(want[keep_mask(want)])
+    assert len(a) == len(b) > 0
+    assert_lines_close(a, b, rel=1e-8, phase_abs=1e-8, what="pure noise")
+
+
 def test_signal_scale_goes_into_the_amplitudes_only(eng):
     """The path is homogeneous in the signal: a signal times 1e30 / 1e120 gives the same T2, F, PH and the amplitudes times the
     factor (the squares of its Hankel entries overflow FP64 for 1e160: out of range for the reference too); times 1e-30 every
