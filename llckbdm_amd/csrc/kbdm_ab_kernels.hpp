@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         const cd zn = ab_update(L.z[root], rho, rhop, L.S[root], &dz);
         zout[j] = zn;
         ws.lastc[a0 + j] = dz;
-        cout[j] = ab_converged(dz, zn, hnorm) ? 1 : 0;
+        cout[j] = (depth == 0 ? ab_converged(dz, zn, hnorm) : ab_converged_inner(dz, zn, hnorm)) ? 1 : 0;
     }
 }
 
