@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ i
     for (int d = dl - 1; d >= 0; --d) {
         ab_subnode(n, d, root < n ? root : 0, sa, sn);
         const bool live = root < n;
+        const bool strict = D == 0 && d == 0;            // only the root of the whole tree is a result; everything else starts its parent
         cd z = live ? ab_perturb(zl[root], a + root, hnorm) : czero();
         __syncthreads();
         if (which == 0 && live) zl[root] = z;
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ i
                 double dz;
                 zn = ab_update(z, rr[0][root], rr[1][root], S, &dz);
                 lastdz = dz;
-                if (ab_converged(dz, zn, hnorm)) settled = true;
+                if (strict ? ab_converged(dz, zn, hnorm) : ab_converged_inner(dz, zn, hnorm)) settled = true;
             }
             __builtin_amdgcn_wave_barrier();
             if (which == 0 && live) zl[root] = zn;
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ i
             const int st_x = __shfl(settled ? 1 : 0, root, 64);
             if (which) settled = st_x != 0;
         }
-        if (which == 0 && live && !ab_acceptable(lastdz, z, hnorm)) failed = 1;
+        if (which == 0 && live && !(strict ? ab_acceptable(lastdz, z, hnorm) : ab_converged_inner(lastdz, z, hnorm))) failed = 1;
     }
     failed = ctx.block_max(failed);
     if (t < n) {
