@@ -31,6 +31,8 @@ constexpr int KB_AB_LEAF = 32;        // largest leaf
 constexpr int KB_AB_BUDGET = 24;      // iterations per level (even: the root buffers alternate)
 constexpr int KB_AB_TILE = 64;        // roots per workgroup
 constexpr int KB_AB_BLK = 32;         // rows per block of the recurrence
+constexpr int KB_AB_INNER_BUDGET = 4;  // iterations of a level below the root of the tree (even: the root buffers alternate)
+static_assert(KB_AB_INNER_BUDGET % 2 == 0, "the root buffers alternate per launch: a level must end on the buffer it started on");
 
 struct AbNode { int a, n; };
 

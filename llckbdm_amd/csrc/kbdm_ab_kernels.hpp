@@ -234,8 +234,11 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     const int j0 = t * per, j1 = (j0 + per < n) ? j0 + per : n;
     {
         int c = 0;
+        // below the root of the tree a level stops after KB_AB_INNER_BUDGET iterations whatever has settled: its eigenvalues
+        // only start the parent (measured on C2: the inner levels' work falls to less than half, the root level's grows by 8 %)
+        const bool capped = depth > 0 && iter >= KB_AB_INNER_BUDGET;
         for (int j = j0; j < j1; ++j) {
-            if (iter != 0 && cin[j]) { zout[j] = zin[j]; cout[j] = 1; }
+            if ((iter != 0 && cin[j]) || capped) { zout[j] = zin[j]; cout[j] = 1; }
             else ++c;
         }
         L.cnt[t] = c;
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     for (int u = 0; u < t; ++u) rank += L.cnt[u];
     if (t == 255) L.flags[0] = rank + L.cnt[255];
     for (int j = j0; j < j1; ++j)
-        if (iter == 0 || !cin[j]) {
+        if ((iter == 0 || !cin[j]) && !(depth > 0 && iter >= KB_AB_INNER_BUDGET)) {
             const int q = rank - tile * KB_AB_TILE;
             if (q >= 0 && q < KB_AB_TILE) L.ridx[q] = j;
             ++rank;

@@ -535,6 +535,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         const bool aberth = ctx->eig_ab && !(pl->mode & KBDM_MODE_SOLO_QR);
         if (aberth) {
             const int Dmax = ab_depth(ch.lmax);
+            int Dmin = Dmax;                                   // steps before Dmin - 1 are inner levels for every member
             std::vector<int> gx(Dmax, 0);                      // workgroups per member and step: tiles x nodes of its level
             {
                 int last_l = -1;
@@ -543,6 +544,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                     if (l == last_l) continue;
                     last_l = l;
                     const int D = ab_depth(l);
+                    Dmin = std::min(Dmin, D);
                     for (int s2 = 0; s2 < D; ++s2) {
                         const int depth = D - 1 - s2;
                         const int Tl = (ab_level_nmax(l, depth) + KB_AB_TILE - 1) / KB_AB_TILE;
@@ -554,7 +556,7 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             hipLaunchKernelGGL(k_ab_leaf, dim3(1 << Dmax, ch.count), dim3(64), sml, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
                                pl->d_dc, pl->d_needqr, sml);
             for (int s2 = 0; s2 < Dmax; ++s2)
-                for (int itn = 0; itn < KB_AB_BUDGET; ++itn)
+                for (int itn = 0; itn < (s2 < Dmin - 1 ? KB_AB_INNER_BUDGET : KB_AB_BUDGET); ++itn)
                     hipLaunchKernelGGL(k_ab_iter, dim3(gx[s2], ch.count), dim3(256), sizeof(AbLds), st, pl->d_items, perm, pl->d_arena,
                                        pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn, pl->d_abstat, env_int("KBDM_AB_DBG", 0));
             hipLaunchKernelGGL(k_ab_finish, dim3(ch.count), dim3(256), KB_RED_BYTES, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
