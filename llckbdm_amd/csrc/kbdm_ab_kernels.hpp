@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ i
         bool settled = !live;
         double lastdz = 0.0;
         const int snmax = (n >> d) + 1;                       // (an upper bound of the node sizes of this depth)
-        for (int iter = 0; iter < 40; ++iter) {
+        for (int iter = 0; iter < (strict ? 40 : KB_AB_INNER_BUDGET); ++iter) {
             if (__ballot(!settled) == 0ull) break;
             // Hyman's recurrence of this lane's root in its node: rows sn-1 .. 0
             if (live) XY[which][sn - 1][root] = which ? czero() : mk(1.0, 0.0);
@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(64) k_ab_leaf(const kb::KbItem* __restrict__ i
             const int st_x = __shfl(settled ? 1 : 0, root, 64);
             if (which) settled = st_x != 0;
         }
-        if (which == 0 && live && !(strict ? ab_acceptable(lastdz, z, hnorm) : ab_converged_inner(lastdz, z, hnorm))) failed = 1;
+        // (below the root of the whole tree an unsettled root is only a worse starting value; a value that is not finite is not)
+        if (which == 0 && live && !(strict ? ab_acceptable(lastdz, z, hnorm) : ab_finite(z))) failed = 1;
     }
     failed = ctx.block_max(failed);
     if (t < n) {
