@@ -58,6 +58,9 @@ const char* kbdm_last_error(void);
 
 /* One context per process and GPU: device selection, stream, module attributes. */
 int kbdm_ctx_create(int device, kbdm_ctx** out);
+/* the same with the number of lanes (concurrent sub-batches by member size) given instead of read from KBDM_LANES; lanes <= 0:
+ * as kbdm_ctx_create.  Results do not depend on it. */
+int kbdm_ctx_create_lanes(int device, int lanes, kbdm_ctx** out);
 int kbdm_ctx_destroy(kbdm_ctx* ctx);
 
 /* A plan fixes the batch geometry (replaces the arguments of sample_kbdm,

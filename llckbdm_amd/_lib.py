@@ -30,6 +30,7 @@ SYMBOLS = {
     "kbdm_device_count": (c_int, []),
     "kbdm_last_error": (c_char_p, []),
     "kbdm_ctx_create": (c_int, [c_int, POINTER(_P)]),
+    "kbdm_ctx_create_lanes": (c_int, [c_int, c_int, POINTER(_P)]),
     "kbdm_ctx_destroy": (c_int, [_P]),
     "kbdm_plan_create": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_double, c_double, POINTER(_P)]),
     "kbdm_plan_destroy": (c_int, [_P]),

@@ -717,7 +717,9 @@ const char* kbdm_stage_name(int stage) {
     return (stage >= 0 && stage < KBDM_NSTAGES) ? kStageNames[stage] : "";
 }
 
-int kbdm_ctx_create(int device, kbdm_ctx** out) {
+int kbdm_ctx_create(int device, kbdm_ctx** out) { return kbdm_ctx_create_lanes(device, 0, out); }
+
+int kbdm_ctx_create_lanes(int device, int nlanes, kbdm_ctx** out) {
     if (!out) return fail(KBDM_E_INVALID, "null out pointer");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KBDM_E_NODEVICE, "no HIP device visible");
@@ -725,7 +727,7 @@ int kbdm_ctx_create(int device, kbdm_ctx** out) {
     HIPCHK(hipSetDevice(device));
     kbdm_ctx* c = new kbdm_ctx();
     c->device = device;
-    c->nlanes = std::min(KB_MAX_LANES, std::max(1, env_int("KBDM_LANES", c->nlanes)));
+    c->nlanes = std::min(KB_MAX_LANES, std::max(1, nlanes > 0 ? nlanes : env_int("KBDM_LANES", c->nlanes)));
     const int hwq = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
     const bool side_all = env_int("KBDM_SIDE_ALL", 0) != 0;
     if (const char* v = getenv("KBDM_LANE0_FRAC")) c->lane0_frac = std::min(0.95, std::max(0.05, atof(v)));
