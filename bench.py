@@ -78,14 +78,25 @@ def _cpu_worker(args):
     return len(O.filter_samples(ll))
 
 
-def cpu_baseline(sig, ms, dwell, min_seconds=12.0, max_passes=8):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(sig, ms, dwell, min_seconds=10.0, max_passes=8, cores=None):
     """Oracle (numpy/scipy: the reference's own LAPACK calls) over the WHOLE C2 member list,
-    one process per host core with 1 BLAS thread each, repeated until >= min_seconds of wall."""
+    one process per host core with 1 BLAS thread each, repeated until >= min_seconds of wall.
+    cores=None: every core this process may run on (len(os.sched_getaffinity(0)))."""
     import multiprocessing as mp
     from threadpoolctl import threadpool_limits
     members = [int(m) for m in ms][::-1]            # longest first: better balance
-    # the GPU box gives each GPU a 16-core host share
-    cores = max(1, min(len(members), 16, len(os.sched_getaffinity(0)), (os.cpu_count() or 1)))
+    avail = max(1, min(len(os.sched_getaffinity(0)), (os.cpu_count() or 1)))
+    cores = max(1, min(len(members), avail if cores is None else min(cores, avail)))
     with threadpool_limits(1):
         ctx = mp.get_context("fork")
         with ctx.Pool(cores) as pool:
@@ -96,7 +107,7 @@ def cpu_baseline(sig, ms, dwell, min_seconds=12.0, max_passes=8):
                 pool.map(_cpu_worker, [(sig, m, dwell) for m in members], chunksize=1)
                 passes += 1
             dt = time.perf_counter() - t0
-    return {"value": passes * len(members) / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+    return {"value": passes * len(members) / dt, "unit": "solves/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": f"{passes} pass(es) over all {len(members)} members of C2, numpy/scipy oracle "
                       f"(zgesdd + zgeev + gemm normaliser), one process per core x {cores}, "
                       f"1 BLAS thread each, {dt:.1f} s wall"}
@@ -173,7 +184,7 @@ def plan_bytes_estimate(ms):
     return float(np.sum(176.0 * np.asarray(ms, dtype=np.float64) ** 2)) + 2e9
 
 
-def run_api_loop(eng, works, steps, nfl, resident, on_done=None):
+def run_api_loop(eng, works, steps, nfl, resident, on_done=None, wide=False):
     """`steps` ensembles through Engine.submit with `nfl` in flight; returns elapsed seconds.  works[k] = (signals,
     sig_idx, ms) of the ensemble that step s = k (mod nfl) solves.  on_done(pending) runs when a step is retired."""
     from collections import deque
@@ -186,7 +197,7 @@ def run_api_loop(eng, works, steps, nfl, resident, on_done=None):
                 on_done(h)
             h.result(check=False)
         sg, si, mm = works[s % nfl]
-        pend.append(eng.submit(sg, si, mm, mm, p=1, q=0.0, dwell=DWELL, resident=resident))
+        pend.append(eng.submit(sg, si, mm, mm, p=1, q=0.0, dwell=DWELL, resident=resident, _wide=wide and nfl == 1))
     while pend:
         h = pend.popleft()
         if on_done:
@@ -196,6 +207,86 @@ def run_api_loop(eng, works, steps, nfl, resident, on_done=None):
 
 
 DWELL = 5e-4
+
+
+def clean_profile(eng, work, reps=3):
+    """One ensemble at a time, the GPU to itself, with the library's per-kernel HIP-event timers on (KBDM_MODE_KERNEL_TIMERS:
+    events on the stream each kernel runs on, around every launch of the timed kernel classes): the basis of the roofline
+    objects.  Returns (stage_ms, {kernel: (total ms, launches)}) averaged over `reps` runs, for lane 0's members."""
+    from llckbdm_amd import _lib
+    sg, si, mm = work
+    eng.drain()
+    sig = np.ascontiguousarray(np.atleast_2d(sg), dtype=np.complex128)
+    plan = eng.cached_plan(sig.shape[0], sig.shape[1], si, mm, mm, 1, 0.0, DWELL)
+    plan.set_mode(_lib.MODE_KERNEL_TIMERS)
+    st_acc, k_acc = {}, {}
+    try:
+        for _ in range(reps + 1):
+            plan.submit(sig)
+            plan.collect()
+            st, km = plan.stage_ms(), plan.kernel_ms()
+            if _ == 0:
+                continue                       # (the first run creates the events)
+            for k, v in st.items():
+                st_acc[k] = st_acc.get(k, 0.0) + v / reps
+            for k, (ms_, n_) in km.items():
+                a = k_acc.get(k, (0.0, 0))
+                k_acc[k] = (a[0] + ms_ / reps, n_)
+    finally:
+        plan.set_mode(0)
+    return st_acc, k_acc
+
+
+def build_rooflines(ms, n0, stage_ms, kernel_ms):
+    """Roofline entries from the clean pass.  Kernels with timers of their own are priced per launch (algorithmic flops or
+    bytes of lane 0's members per launch / average launch duration); the remaining stages by their stage timer."""
+    lane0 = sorted((int(m) for m in ms), reverse=True)[:n0]
+    fl = {}
+    for m in lane0:
+        for k, v in stage_flops(m, m).items():
+            fl[k] = fl.get(k, 0.0) + v
+    npan = lambda m: (m - 64) // 32 if m >= 96 else 0
+    # the one-stage panels stream the trailing matrix twice (bidiagonalisation) / once (Hessenberg: all rows x the trailing
+    # columns) per column: the bytes of the ALGORITHM, not compulsory traffic
+    b_bidiag = sum(sum(2 * 16.0 * (m - c) ** 2 for c in range(npan(m) * 32)) for m in lane0)
+    b_hess = sum(sum(16.0 * m * (m - c - 1) for c in range(npan(m) * 32)) for m in lane0)
+    b_hankel = sum(16.0 * m * m + 16.0 * (2 * m - 1) for m in lane0)
+    # flops of the blocked reductions inside their panel columns: half in the panel's matrix-vector products, half in the update
+    f_trail = sum(sum(8.0 * 64 * (m - 32 * (p + 1)) ** 2 for p in range(npan(m))) for m in lane0)     # rank-64 complex updates
+    f_hupd = sum(sum(8.0 * 64 * m * (m - 32 * (p + 1)) for p in range(npan(m))) for m in lane0)
+    spec = {   # kernel: (bound, algorithmic quantity over all launches of the stage, unit, note)
+        "k_ab_iter": ("mfma", fl["k_hqr"], "flop", "eigenvalue stage (Ehrlich-Aberth): 65.33 l^3 per member (SURVEY 8d)"),
+        "k_bidiag_panel_team": ("hbm", b_bidiag, "B", "two passes over the trailing matrix per panel column, 32 (n - j)^2 B"),
+        "k_hess_panel_team": ("hbm", b_hess, "B", "one pass over all rows x the trailing columns per panel column, 16 n (n - k - 1) B"),
+        "k_trail_update": ("mfma", f_trail, "flop", "rank-64 trailing update: the zgemm half of the blocked bidiagonalisation (north_star's SVD panel update)"),
+        "k_hess_update": ("mfma", f_hupd, "flop", "rank-64 update of the Hessenberg reduction"),
+        "k_hankel": ("hbm", b_hankel, "B", "16 m^2 B written + the signal segment read per member (pipeline: U^{p-1} only)"),
+    }
+    out = []
+    for kname, (bound, qty, unit, note) in spec.items():
+        tot, n = kernel_ms.get(kname, (0.0, 0))
+        if n <= 0 or tot <= 0:
+            continue
+        avg_ms = tot / n
+        per_launch = qty / n
+        if bound == "mfma":
+            ach = per_launch / (avg_ms * 1e-3) / 1e12
+            peak, u = FP64_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            peak, u = HBM_PEAK_GBS, "GB/s"
+        out.append({"kernel": kname, "bound": bound, "achieved": ach, "peak": peak, "unit": u, "frac": ach / peak,
+                    "avg_ms": avg_ms, "launches": n, "total_ms": tot,
+                    ("algorithmic_flops_per_launch" if unit == "flop" else "algorithmic_bytes_per_launch"): per_launch,
+                    "launch_members": n0, "note": note})
+    out.sort(key=lambda r: -r["total_ms"])
+    stages = []
+    for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1]):
+        if v <= 0:
+            continue
+        a = fl.get(k, 0.0) / (v * 1e-3) / 1e12
+        stages.append({"stage": k, "ms": v, "algorithmic_flops": fl.get(k, 0.0), "achieved_tflops": a, "frac_fp64": a / FP64_PEAK_TFLOPS})
+    return out, stages[:6]
 
 
 def main():
@@ -342,7 +433,7 @@ def main():
         ok_all = [ok]
 
     # ---- the same steps one at a time, host -> host, and the other configurations (N = 1 only)
-    serial = host_incl = None
+    serial = host_incl = clean = sample_call = llc_call = None
     others = {}
     if not multi:
         ns_ser = min(args.steps, 5)
@@ -353,15 +444,47 @@ def main():
                 for name, v in h.plan.stage_ms().items():
                     ser_acc[name] = ser_acc.get(name, 0.0) + v
                 ser_n[0] += 1
-            ts = run_api_loop(eng, [works[0]], ns_ser, 1, resident=True, on_done=ser_done)
+            run_api_loop(eng, [works[0]], 2, 1, resident=True, wide=True)              # (plan + warm-up of that context)
+            ts = run_api_loop(eng, [works[0]], ns_ser, 1, resident=True, on_done=ser_done, wide=True)
             serial = {"value": units * ns_ser / ts, "ms_per_step": 1e3 * ts / ns_ser, "steps": ns_ser, "ensembles_in_flight": 1,
+                      "context": "the engine's context for synchronous calls (panel teams: Engine.WIDE_*), as Engine.solve uses it",
                       "stage_ms": {k: v / max(1, ser_n[0]) for k, v in ser_acc.items()}}
+        # the clean pass behind the roofline objects: one ensemble at a time with the per-kernel timers on
+        clean = None
+        try:
+            clean = clean_profile(eng, works[0])
+        except Exception as e:
+            clean = None
+            print("clean_profile failed:", repr(e), file=sys.stderr)
+        sample_call = llc_call = None
+        if args.workload in ("C2", "NS"):
+            # ONE call of the drop-in sampler (what llc_kbdm makes: llckbdm.py:76-83), host signal in, python line lists out
+            from llckbdm_amd.sampling import sample_kbdm
+            sg0 = works[0][0][0]
+            mr = [int(x) for x in ms]
+            sample_kbdm(sg0, DWELL, mr, p=1, l=None, q=0, engine=eng)
+            tsc = time.perf_counter()
+            nrep = 3
+            for _ in range(nrep):
+                sample_kbdm(sg0, DWELL, mr, p=1, l=None, q=0, engine=eng)
+            tsc = (time.perf_counter() - tsc) / nrep
+            sample_call = {"value": len(mr) / tsc, "unit": "solves/s", "ms_per_call": 1e3 * tsc,
+                           "api": "llckbdm_amd.sampling.sample_kbdm(data, dwell, m_range, p, l, q): one synchronous call, host -> host"}
         if not args.no_extras:
+            if args.workload == "C2":
+                try:
+                    from llckbdm_amd.llckbdm import llc_kbdm
+                    tl = time.perf_counter()
+                    res_llc = llc_kbdm(works[0][0][0], DWELL, [int(x) for x in ms], p=1, l=None, q=0.0, engine=eng)
+                    llc_call = {"seconds": time.perf_counter() - tl, "lines": int(len(res_llc.line_list)),
+                                "api": "llckbdm_amd.llckbdm.llc_kbdm on the C2 ensemble: sampler + 150-fit clustering sweep + scoring"}
+                except Exception as e:
+                    llc_call = {"error": repr(e)}
             # SURVEY.md 8d's wording of the metric: host signals resident -> host line lists resident, through the same
             # public API, the same number of ensembles in flight
             nh = args.steps
             th = run_api_loop(eng, works, nh, nfl, resident=False)
-            th1 = run_api_loop(eng, [works[0]], ns_ser, 1, resident=False)
+            th1 = run_api_loop(eng, [works[0]], ns_ser, 1, resident=False, wide=True)
             host_incl = {"value": units * nh / th, "unit": "solves/s", "ms_per_step": 1e3 * th / nh, "steps": nh,
                          "ensembles_in_flight": nfl, "one_ensemble_at_a_time": units * ns_ser / th1,
                          "includes": "Engine.submit -> Pending.result: staging + H2D of the signal, every kernel, D2H of "
@@ -408,50 +531,55 @@ def main():
         for m in ms:
             for k, v in stage_flops(m, m).items():
                 fl_all[k] = fl_all.get(k, 0.0) + v
-        dom = max(stage_ms, key=lambda k: stage_ms[k])
-        achieved = fl[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
-        # the kernel behind the dominant stage timer (lane 0 runs the QR iteration as the team kernel)
-        kname = {"k_hqr": "k_ab_iter" if os.environ.get("KBDM_EIG_AB", "1") != "0" else "k_hqr2_team",
-                 "k_svd_fac": "k_bidiag_panel<0>", "k_hess": "k_hess_panel",
-                 "k_gen(Q,P)": "k_wy_update", "k_dc_final": "k_dc_final", "k_invit": "k_invit_reg<8>"}.get(dom, dom)
-        # HBM bytes per launch of that kernel: NOT measured by this run - taken from the newest committed PMC passes
-        # (profiles/*_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command), if any
-        traffic = traffic_src = None
-        try:
-            import glob
-            def newest_first(fn):          # r<round>_<milestone>_pmc_traffic.json: later round, then fin > end / last > mid > others
-                tag = os.path.basename(fn).split("_")
-                return (tag[0], {"fin": 3, "end": 2, "last": 2, "mid": 1}.get(tag[1], 0))
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=newest_first, reverse=True):
-                pmc = json.load(open(fn))["kernels"]
-                if kname in pmc:
-                    traffic = pmc[kname].get("hbm_bytes_per_launch")
-                    traffic_src = "profiles/" + os.path.basename(fn) + " (committed rocprofv3 PMC passes, not this run)"
-                    break
-        except Exception:
-            traffic = None
-        roofline = {"kernel": kname, "stage_timer": dom,
-                    "bound": "mfma" if kname in ("k_trail_update", "k_hess_update", "k_ab_iter") else "fp64_vector",
-                    "bound_note": ("eigenvalue stage: Ehrlich-Aberth iterations (k_ab_iter: FP64-MFMA block products + a serial "
-                                   "32-row triangle per block), priced with the stage's algorithmic 65.33 l^3 flops per member "
-                                   "(SURVEY.md 8d) over the stage's HIP-event time" if kname == "k_ab_iter" else
-                                   "FP64 vector FMA, instruction-issue / latency bound; MI355X FP64 vector peak = FP64 matrix "
-                                   "peak = 78.6 TFLOP/s"),
-                    "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_ms": stage_ms[dom], "algorithmic_flops_per_launch": fl[dom],
-                    "launch_members": n0}
-        if kname == "k_ab_iter":
-            roofline["launches_per_stage"] = "k_ab_leaf + 24 x levels k_ab_iter + k_ab_finish; `traffic` is ONE k_ab_iter launch"
-        if serial and serial.get("stage_ms", {}).get(dom, 0) > 0:
-            # the same stage with the GPU to itself (in the timed region four ensembles share the CUs, so a stage's HIP-event
-            # time there is its share of a busy chip, not its cost)
-            alone = fl[dom] / (serial["stage_ms"][dom] * 1e-3) / 1e12
-            roofline["one_ensemble_at_a_time"] = {"avg_ms": serial["stage_ms"][dom], "achieved": alone, "frac": alone / FP64_PEAK_TFLOPS}
         total_fl = sum(fl_all.values())
-        pipe = total_fl * args.steps * (1 if args.sharded else world) / elapsed / 1e12
-        roofline["whole_pipeline"] = {"achieved": pipe, "frac": pipe / (FP64_PEAK_TFLOPS * world), "unit": "TFLOP/s",
-                                      "note": "algorithmic flops of every stage of every member (SURVEY.md 8d) over the timed region"}
+        nj = (1 if args.sharded else world)
+        pipe = total_fl * args.steps * nj / elapsed / 1e12
+        pipe216 = 216.0 * float(np.sum(np.asarray(ms, dtype=np.float64) ** 3)) * args.steps * nj / elapsed / 1e12
+        roofline = None
+        if clean is not None:
+            kern, stages = build_rooflines(ms, n0, clean[0], clean[1])
+            if kern:
+                roofline = dict(kern[0])
+                roofline["measured"] = ("one ensemble at a time, the GPU to itself: HIP events recorded by the library on the "
+                                        "stream the kernel runs on, around every launch (KBDM_MODE_KERNEL_TIMERS)")
+                # HBM bytes per launch of that kernel from the newest committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+                # WRITE_SIZE, gfx950 correction applied: profiles/*_pmc_traffic.json) - not measured by this run
+                traffic = traffic_src = None
+                try:
+                    import glob
+                    def newest_first(fn):
+                        tag = os.path.basename(fn).split("_")
+                        return (tag[0], {"fin": 3, "end": 2, "last": 2, "mid": 1}.get(tag[1], 0))
+                    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=newest_first, reverse=True):
+                        pmc = json.load(open(fn))["kernels"]
+                        hit = [k for k in pmc if k.split("<")[0] == roofline["kernel"].split("<")[0]]
+                        if hit:
+                            traffic = pmc[hit[0]].get("hbm_bytes_per_launch")
+                            traffic_src = "profiles/" + os.path.basename(fn) + " (committed rocprofv3 PMC passes, not this run)"
+                            break
+                except Exception:
+                    traffic = None
+                roofline["traffic"] = traffic
+                roofline["traffic_source"] = traffic_src
+                roofline["top_kernels"] = kern[:5]
+                roofline["top_stages"] = stages
+                tu = next((r for r in kern if r["kernel"] == "k_trail_update"), None)
+                hu = next((r for r in kern if r["kernel"] == "k_hess_update"), None)
+                hk2 = next((r for r in kern if r["kernel"] == "k_hankel"), None)
+                roofline["north_star"] = {
+                    "mfma_util_svd_panel_update": None if tu is None else tu["frac"],
+                    "mfma_util_hess_update": None if hu is None else hu["frac"],
+                    "hankel_build_GBps_c2_launch": None if hk2 is None else hk2["achieved"],
+                    "note": "MFMA utilisation = algorithmic flops of the rank-64 update launches / their HIP-event time / 78.6 "
+                            "TFLOP/s, over ALL launches of lane 0 in the clean pass; the Hankel build on a chip-filling launch: "
+                            "other_configs.C3.hankel_build"}
+        if roofline is None:
+            roofline = {"kernel": None, "bound": "mfma", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                        "traffic": None, "note": "no clean pass in this mode (N > 1): see the N = 1 line"}
+        roofline["whole_pipeline"] = {"achieved": pipe216, "frac": pipe216 / (FP64_PEAK_TFLOPS * world), "unit": "TFLOP/s",
+                                      "flops_per_member": "216 m^3 (SURVEY.md 8d: F_alg at l = m) over the timed region",
+                                      "by_stage_model": {"achieved": pipe, "note": "sum of the per-stage algorithmic counts this "
+                                                         "file's stage_flops() prices the stages with (167 m^3)"}}
         out = {
             "metric": "KBDM solves/sec over m-range ensemble, N=2048 complex signal",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -463,11 +591,15 @@ def main():
                                        else f"one ensemble per rank x{world}"),
                        "ensembles_in_flight": nfl,
                        "api": "llckbdm_amd.engine.Engine.submit / Pending.result (the product's scheduler)",
-                       "timed_region": "signals resident in HBM -> results in host memory (host -> host: `host_to_host`)",
+                       "timed_region": "signals resident in HBM when the clock starts -> results in host memory (the bench "
+                                       "contract); SURVEY 8d's host -> host unit is `value_host_to_host` / `host_to_host`",
                        "collective": ("one grouped RCCL send/recv of the packed results to rank 0 per step (kbdm_plan_gather)"
                                       if multi else "none")},
             "roofline": roofline,
-            "pipeline_tflops": total_fl * args.steps * (1 if args.sharded else world) / elapsed / 1e12,
+            "value_host_to_host": None if host_incl is None else host_incl["value"],
+            "sample_kbdm_call": sample_call,
+            "llc_kbdm_c2": llc_call,
+            "pipeline_tflops": pipe216,
             "stage_ms": stage_ms,
             "step_latency_ms": None if latency is None else 1e3 * latency,
             "one_ensemble_at_a_time": serial,
@@ -476,6 +608,7 @@ def main():
             "eig_fallbacks_last_step": nfb,
             "members_ok": min(ok_all), "members_ok_per_rank": ok_all,
             "gathered_blocks_verified": gathered_ok[0] if multi else None,
+            "rccl_world_seen": (sorted(set(int(c.world) for c in comms.values())) if multi else None),
             "gather_host_ms_per_call": 1e3 * gather_t[1] / max(1, gather_t[2]) if multi else None,
             "git_head": git_head(), "bench_sha256_16": file_sha(os.path.abspath(__file__)),
             "lib_sha256_16": file_sha(_lib.LIB_PATH),
@@ -484,8 +617,10 @@ def main():
             try:
                 if args.workload in ("C2", "NS"):
                     sig0 = make_workload(args.workload, rank)[0][0]
-                    out["cpu_baseline"] = cpu_baseline(sig0, ms, DWELL)
-                    out["cpu_baseline"]["serial"] = cpu_baseline_serial(sig0, ms, DWELL)
+                    out["cpu_baseline"] = cpu_baseline(sig0, ms, DWELL)                       # every core of the box
+                    if out["cpu_baseline"]["cores"] > 16:                                      # and the 16-core host share of one GPU
+                        out["cpu_baseline"]["host_share_16_cores"] = cpu_baseline(sig0, ms, DWELL, min_seconds=6.0, cores=16)
+                    out["cpu_baseline"]["serial"] = cpu_baseline_serial(sig0, ms, DWELL, stride=8)
                 else:
                     out["cpu_baseline"] = None
             except Exception as e:   # the baseline is informational; never lose the GPU number over it

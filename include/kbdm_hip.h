@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define KBDM_ABI_VERSION 2
+#define KBDM_ABI_VERSION 3
 
 #define KBDM_OK 0
 #define KBDM_E_INVALID (-1)   /* bad argument (sizes, null pointers, m/l/p constraint) */
@@ -62,6 +62,13 @@ int kbdm_ctx_create(int device, kbdm_ctx** out);
  * as kbdm_ctx_create.  Results do not depend on it. */
 int kbdm_ctx_create_lanes(int device, int lanes, kbdm_ctx** out);
 int kbdm_ctx_destroy(kbdm_ctx* ctx);
+/* Cooperative panels: the two panel kernels of the blocked reductions (the serial chains of a member: bidiagonalisation,
+ * Hessenberg reduction) run with teams of up to T workgroups per member of lane 0 (all_lanes != 0: of every lane) whenever
+ * count x T workgroups fit `budget`.  The workgroups of a team wait for each other, so all teams of a launch must be
+ * resident: keep the SUM of the budgets of the contexts that may run at the same time on one GPU at or below its number of
+ * compute units (256).  lane0_frac > 0 also sets lane 0's share of a batch's cost (teams shorten lane 0's chain, so it can
+ * take more).  Results do not depend on any of this (a member gets the same bits from a team of any size).  Default: T = 1. */
+int kbdm_ctx_set_panel_teams(kbdm_ctx* ctx, int T, int budget, int all_lanes, double lane0_frac);
 
 /* A plan fixes the batch geometry (replaces the arguments of sample_kbdm,
  * sampling.py:8: data/m_range/p/l/q, for many signals at once) and owns the device
@@ -92,7 +99,28 @@ int kbdm_plan_collect(kbdm_plan* plan, double* lines, double* sv, double* mu, ui
  *   KBDM_MODE_SOLO_QR      every member's QR iteration runs in one workgroup (no chase + helper teams: the one place
  *                          where workgroups of a launch wait for each other) */
 #define KBDM_MODE_SOLO_QR 2
+/*   KBDM_MODE_KERNEL_TIMERS a measuring mode (bench.py's roofline): pairs of HIP events around every launch of the kernel
+ *                          classes below, on the stream the kernel runs on; read with kbdm_plan_kernel_ms */
+#define KBDM_MODE_KERNEL_TIMERS 4
 int kbdm_plan_set_mode(kbdm_plan* plan, int mode);
+/* Kernel classes of the per-kernel timers; lane 0's launches (the largest members) are the ones timed. */
+#define KBDM_K_HANKEL 0
+#define KBDM_K_BIDIAG_PANEL 1
+#define KBDM_K_TRAIL_UPDATE 2
+#define KBDM_K_HESS_PANEL 3
+#define KBDM_K_HESS_Z 4
+#define KBDM_K_HESS_UPDATE 5
+#define KBDM_K_AB_ITER 6
+#define KBDM_K_WY_APPLY 7
+#define KBDM_NKCLASSES 8
+const char* kbdm_kernel_class_name(int klass);
+/* Sum of the HIP-event durations of the launches of `klass` in the last KBDM_MODE_KERNEL_TIMERS run and their number
+ * (k_ab_iter: one bracket around its back-to-back launches); waits for the plan. */
+int kbdm_plan_kernel_ms(kbdm_plan* plan, int klass, float* total_ms, int32_t* launches);
+/* Test hook of the status contract (tests/test_gpu_api_r3.py), process-wide: kbdm_plan_download / kbdm_plan_collect OR
+ * `always` into every member's status word, and `once` into the words of the NEXT collected run only.  (0, 0) disarms it.
+ * Nothing on the result path reads the environment. */
+int kbdm_debug_force_status(int always, int once);
 /* device bytes a plan of this geometry will allocate (before chunking) / a plan holds */
 int64_t kbdm_workspace_estimate(int B, const int32_t* m, const int32_t* l);
 int64_t kbdm_plan_workspace_bytes(const kbdm_plan* plan);
@@ -129,9 +157,12 @@ int kbdm_plan_ab_stats(kbdm_plan* plan, int32_t* out, int n);
  * variable-length gather of every rank's packed results over xGMI.  The library binds librccl.so itself (dlopen); the
  * context owns the communicator.  Launcher protocol: rank 0 calls kbdm_comm_unique_id and hands the 128 bytes to the
  * other ranks by whatever means the launcher has (before any collective); every rank then calls kbdm_comm_init.
- * A rank's packed block is  [lines: L x 4 f64][sv: SV f64][status: B i32][keep: L u8][pad to 16 B]  for its L lines,
- * SV singular values and B members; kbdm_packed_bytes gives its size, so every rank can size every other rank's block
- * from the (deterministic) shard table alone: no size exchange, no host bounce. */
+ * A rank's packed block is  [lines: L x 4 f64][sv: SV f64][status: B i32][keep: L u8][pad to 16 B][trailer: 16 B]  for its
+ * L lines, SV singular values and B members; kbdm_packed_bytes gives its size, so every rank can size every other rank's
+ * block from the (deterministic) shard table alone: no size exchange, no host bounce.  The trailer is
+ * {u32 magic "KBDM", u32 sender rank, u64 sequence number of the gather}: the receiver checks on the device that every
+ * block it got belongs to THIS gather (ABI 3), so ranks that issue their gathers in different orders get an error from
+ * kbdm_gather_wait instead of each other's steps. */
 #define KBDM_UNIQUE_ID_BYTES 128
 int kbdm_comm_unique_id(unsigned char* id_out);
 int kbdm_comm_init(kbdm_ctx* ctx, int world, int rank, const unsigned char* id);
@@ -148,8 +179,10 @@ int64_t kbdm_packed_bytes(int64_t lines, int64_t sv, int64_t members);
 int kbdm_plan_gather(kbdm_plan* plan, int world, int rank, const int64_t* bytes, int root, void* host_out);
 /* The transfer runs on a communication stream of the context behind an event of the plan's stream: with host_out = null
  * kbdm_plan_gather only ENQUEUES it and returns (the plan's context can take its next run at once; its pack buffer is
- * reused only after the transfer); kbdm_gather_wait blocks until the context's last gather has landed.  With host_out
- * the call itself waits. */
+ * reused only after the transfer); kbdm_gather_wait blocks until the context's last gather has landed - for at most
+ * KBDM_GATHER_TIMEOUT_S seconds (environment, default 300): a peer that died leaves the transfer hanging, the wait then
+ * returns KBDM_E_HIP so that the process can exit and its launcher tear the job down - and reports a trailer mismatch as
+ * KBDM_E_HIP too.  With host_out the call itself waits. */
 int kbdm_gather_wait(kbdm_ctx* ctx);
 void* kbdm_gathered_device(kbdm_ctx* ctx);
 

@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libkbdm_hip.so")
+# (KBDM_LIB: a diagnostic build of the same sources, e.g. tools/panel_phases.py's library with phase timers)
+LIB_PATH = os.environ.get("KBDM_LIB") or os.path.join(_PKG, "libkbdm_hip.so")
 
 # A plan runs on three HIP streams (two lanes + the critical lane's side stream) and an Engine keeps up to three
 # contexts in flight.  The ROCm runtime maps streams onto four hardware queues by default; streams that share a queue
@@ -17,11 +18,13 @@ LIB_PATH = os.path.join(_PKG, "libkbdm_hip.so")
 # process yet; never overrides the user's own setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-KBDM_ABI_VERSION = 2
+KBDM_ABI_VERSION = 3
 KBDM_NSTAGES = 16
 KBDM_UNIQUE_ID_BYTES = 128
 STAT_SVD_NOCONV, STAT_EIG_NOCONV, STAT_INVIT_WEAK = 1, 2, 4
 MODE_SOLO_QR = 2
+MODE_KERNEL_TIMERS = 4
+KBDM_NKCLASSES = 8
 
 # every symbol include/kbdm_hip.h declares: (restype, argtypes)
 _P = c_void_p
@@ -32,6 +35,7 @@ SYMBOLS = {
     "kbdm_ctx_create": (c_int, [c_int, POINTER(_P)]),
     "kbdm_ctx_create_lanes": (c_int, [c_int, c_int, POINTER(_P)]),
     "kbdm_ctx_destroy": (c_int, [_P]),
+    "kbdm_ctx_set_panel_teams": (c_int, [_P, c_int, c_int, c_int, c_double]),
     "kbdm_plan_create": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_double, c_double, POINTER(_P)]),
     "kbdm_plan_destroy": (c_int, [_P]),
     "kbdm_plan_total_lines": (c_int64, [_P]),
@@ -45,6 +49,9 @@ SYMBOLS = {
     "kbdm_plan_submit": (c_int, [_P, _P]),
     "kbdm_plan_collect": (c_int, [_P, _P, _P, _P, _P, _P]),
     "kbdm_plan_set_mode": (c_int, [_P, c_int]),
+    "kbdm_debug_force_status": (c_int, [c_int, c_int]),
+    "kbdm_kernel_class_name": (c_char_p, [c_int]),
+    "kbdm_plan_kernel_ms": (c_int, [_P, c_int, _P, _P]),
     "kbdm_workspace_estimate": (c_int64, [c_int, _P, _P]),
     "kbdm_plan_workspace_bytes": (c_int64, [_P]),
     "kbdm_plan_lines_device": (_P, [_P]),

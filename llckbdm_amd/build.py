@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkbdm_hip.so")
 SOURCES = ["kbdm_hip.hip"]
-HEADERS = ["kbdm_kernels.hpp", "kbdm_device.h", "kb_complex.hpp", "kb_ctx.hpp", "kb_svd.hpp", "kb_eig.hpp", "kb_hqr_ms.hpp", "kb_hqr2.hpp", "kb_bdsdc.hpp", "kbdm_dc_kernels.hpp", "kb_aberth.hpp", "kbdm_ab_kernels.hpp", "kbdm_next.hpp", "kbdm_cluster.hpp",
+HEADERS = ["kbdm_kernels.hpp", "kbdm_device.h", "kb_complex.hpp", "kb_ctx.hpp", "kb_svd.hpp", "kb_eig.hpp", "kb_hqr_ms.hpp", "kb_hqr2.hpp", "kb_bdsdc.hpp", "kbdm_dc_kernels.hpp", "kb_aberth.hpp", "kbdm_ab_kernels.hpp", "kbdm_next.hpp", "kbdm_cluster.hpp", "kb_team.hpp", "kb_panel_team.hpp",
            os.path.join("..", "..", "include", "kbdm_hip.h")]
 
 

@@ -27,6 +27,12 @@ struct DevCtx {
     __device__ __forceinline__ int wave() const { return threadIdx.x >> 6; }
     __device__ __forceinline__ int nwaves() const { return blockDim.x >> 6; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // Barrier for data exchanged through LDS only: waits for this wavefront's LDS operations, NOT for its outstanding global
+    // stores (__syncthreads waits for their acknowledgement: 1-2 us when a phase has just stored a vector to memory).
+    // Global memory written before it is NOT ordered for the other wavefronts.
+    __device__ __forceinline__ void sync_lds() const {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     // order this wavefront's LDS/global writes before later reads by its other lanes
     __device__ __forceinline__ void wave_fence() const {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -69,6 +75,15 @@ struct DevCtx {
         v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
         return v;
     }
+    // sum over each group of eight adjacent lanes (identical bits in the eight): ((l0+l1)+(l2+l3)) + ((l4+l5)+(l6+l7))
+    static constexpr int OCT = 8;
+    __device__ __forceinline__ double oct_sum(double v) const {
+        v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+        v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+        v += dpp_f64<0x141>(v);     // row_half_mirror
+        return v;
+    }
+    __device__ __forceinline__ cd oct_sum(cd v) const { return mk(oct_sum(v.x), oct_sum(v.y)); }
     __device__ __forceinline__ double wave_sum(double v) const {
         v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
         v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
@@ -108,6 +123,29 @@ struct DevCtx {
         const int nw = nwaves();
         for (int w = 0; w < nw; ++w) t += red[w];
         __syncthreads();
+        return t;
+    }
+    // the same with LDS-only barriers (sync_lds)
+    __device__ __forceinline__ double block_sum_l(double v) const {
+        double* red = reinterpret_cast<double*>(smem);
+        v = wave_sum(v);
+        if (lane() == 0) red[wave()] = v;
+        sync_lds();
+        double t = 0.0;
+        const int nw = nwaves();
+        for (int w = 0; w < nw; ++w) t += red[w];
+        sync_lds();
+        return t;
+    }
+    __device__ __forceinline__ double block_max_l(double v) const {
+        double* red = reinterpret_cast<double*>(smem);
+        v = wave_max(v);
+        if (lane() == 0) red[wave()] = v;
+        sync_lds();
+        double t = red[0];
+        const int nw = nwaves();
+        for (int w = 1; w < nw; ++w) t = fmax(t, red[w]);
+        sync_lds();
         return t;
     }
     __device__ __forceinline__ cd block_sum(cd v) const {
@@ -158,6 +196,12 @@ struct HostCtx {
     int wave() const { return 0; }
     int nwaves() const { return 1; }
     void sync() const {}
+    void sync_lds() const {}
+    static constexpr int OCT = 1;
+    double oct_sum(double v) const { return v; }
+    cd oct_sum(cd v) const { return v; }
+    double block_sum_l(double v) const { return v; }
+    double block_max_l(double v) const { return v; }
     void wave_fence() const {}
     void lds_fence() const {}
     void lds_order() const {}

@@ -13,6 +13,8 @@
 #include <string>
 #include <limits>
 #include <thread>
+#include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "../../include/kbdm_hip.h"
@@ -59,6 +61,11 @@ struct DevBufs {
         return e;
     }
 };
+
+// Test hooks (kbdm_debug_force_status): status bits that kbdm_plan_download / kbdm_plan_collect OR into every member's word
+// - always / in the next collected run only.  Set explicitly through the C ABI by the tests of the status contract; no
+// environment variable is read on the result path.
+std::atomic<int> g_force_status{0}, g_force_status_once{0};
 
 int env_int(const char* name, int def) {
     const char* v = getenv(name);
@@ -115,6 +122,13 @@ struct kbdm_ctx {
     int eig_ab = 1;       // eigenvalues by divide-and-conquer Ehrlich-Aberth (kb_aberth.hpp), QR iteration as the fallback;
                           // 0: QR iteration for every member (KBDM_EIG_AB)
     int team_max = 112;   // teams in flight over all lanes: 2 workgroups each, one workgroup per CU, all resident
+    int panel_T = 1;      // cooperative panels (kb_team.hpp): workgroups per member of lane 0 in the two panel kernels ...
+    int panel_budget = 64;    // ... as long as all teams of the launch fit this many workgroups (they wait for each other, so
+                          // they must all be resident: the sum over the contexts of a process must stay below the CU count)
+    int panel_T_all = 0;  // KBDM_PANEL_T_ALL=1: teams on every lane (the budget then counts per lane)
+    int panel_old = 0;    // KBDM_PANEL_OLD=1: the round-3 one-workgroup panels (A/B)
+    int ab_dbg = 0;       // KBDM_AB_DBG, read once when the context is created: 8 = phase timers of k_ab_iter (tools/ab_phases.py);
+                          // the bits that skip work (2, 4: timing experiments, wrong results) exist in -DKBDM_DEBUG_BUILD libraries only
     double ws_budget_gib = 96.0;
     // multi-GPU: RCCL communicator (one per context) and the device buffers of the packed gather
     void* comm = nullptr;
@@ -123,6 +137,7 @@ struct kbdm_ctx {
     hipStream_t comm_stream = nullptr;        // the gather runs here, behind an event of the plan's stream
     hipEvent_t ev_packed = nullptr, ev_gathered = nullptr;
     bool gather_pending = false;
+    int* d_gather_bad = nullptr;              // set by k_check_trailers when a received block is not the one this step expects
     char* d_pack = nullptr;
     char* d_gather = nullptr;
     size_t pack_cap = 0, gather_cap = 0;
@@ -134,7 +149,14 @@ struct Chunk {
     int group = 0;              // workspace generation: groups run one after the other (they share the arena)
     int lane = 0;               // chunks of one group run concurrently, one per lane
     std::vector<hipEvent_t> ev;
+    // opt-in per-kernel timers (KBDM_MODE_KERNEL_TIMERS): pairs of events around the launches of a kernel class
+    std::vector<hipEvent_t> kev[KBDM_NKCLASSES];
+    int kused[KBDM_NKCLASSES] = {0};       // events used by the current run (2 per bracket)
+    int klaunches[KBDM_NKCLASSES] = {0};   // kernel launches inside the brackets
 };
+
+const char* kKernelClassNames[KBDM_NKCLASSES] = {"k_hankel", "k_bidiag_panel_team", "k_trail_update", "k_hess_panel_team",
+                                                 "k_hess_z", "k_hess_update", "k_ab_iter", "k_wy_apply"};
 
 struct kbdm_plan {
     kbdm_ctx* ctx = nullptr;
@@ -161,6 +183,7 @@ struct kbdm_plan {
     unsigned char* d_keep = nullptr;
     int* d_status = nullptr;
     TeamCtl* d_team = nullptr;     // one control block per member
+    PanelTeamCtl* d_pteam = nullptr;   // cooperative panels: one control block per sorted position
     char* d_rings = nullptr;       // KB_TEAM_SLOTS records per member
     float stage_ms[KBDM_NSTAGES] = {0};
     bool timed = false;
@@ -191,6 +214,8 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_tfac), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_apply), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_APPLY_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_invit), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -315,6 +340,8 @@ int plan_alloc(kbdm_plan* pl) {
     HIPCHK(hipMalloc(&pl->d_iwork, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
     HIPCHK(hipMemset(pl->d_iwork, 0, sizeof(int) * (4 * std::max(B, 1) + KB_QUEUE_WORDS)));
     HIPCHK(hipMalloc(&pl->d_team, sizeof(TeamCtl) * std::max(B, 1)));
+    HIPCHK(hipMalloc(&pl->d_pteam, sizeof(PanelTeamCtl) * std::max(B, 1)));
+    HIPCHK(hipMemset(pl->d_pteam, 0, sizeof(PanelTeamCtl) * std::max(B, 1)));
     HIPCHK(hipMalloc(&pl->d_rings, (size_t)std::max(B, 1) * KB_TEAM_SLOTS *
                                        team2_rec_bytes(pl->ctx->win_hqr2)));
     HIPCHK(hipMalloc(&pl->d_dc, sizeof(double) * std::max<size_t>(pl->dc_elems, 1)));
@@ -335,6 +362,7 @@ struct StageTimer {
             ch->ev.resize(KBDM_NSTAGES + 1);
             for (auto& e : ch->ev) HIPCHK(hipEventCreate(&e));
         }
+        for (int k = 0; k < KBDM_NKCLASSES; ++k) { ch->kused[k] = 0; ch->klaunches[k] = 0; }
         HIPCHK(hipEventRecord(ch->ev[0], pl->ctx->lanes[ch->lane].stream));
         idx = 1;
         return KBDM_OK;
@@ -346,7 +374,43 @@ struct StageTimer {
     }
 };
 
+// Bracket `launches` launches of kernel class k on stream st with a pair of events (only in KBDM_MODE_KERNEL_TIMERS runs:
+// the events cost host time and a little stream time, so the throughput runs do without).
+struct KBracket {
+    kbdm_plan* pl; Chunk* ch; int k; hipStream_t st; bool on;
+    KBracket(kbdm_plan* pl_, Chunk& ch_, int k_, hipStream_t st_, int launches) : pl(pl_), ch(&ch_), k(k_), st(st_) {
+        on = (pl->mode & KBDM_MODE_KERNEL_TIMERS) != 0;
+        if (!on) return;
+        mark();
+        ch->klaunches[k] += launches;
+    }
+    ~KBracket() { if (on) mark(); }
+    void mark() {
+        auto& v = ch->kev[k];
+        if ((int)v.size() <= ch->kused[k]) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } v.push_back(e); }
+        hipEventRecord(v[ch->kused[k]++], st);
+    }
+};
+
 int smem_fac(int n, int nt) { return KB_RED_BYTES + bidiag_scratch_bytes(n, nt / 64, 64); }
+
+// Cooperative panels: workgroups per member of this chunk's panel launches.  A team's workgroups wait for each other, so a
+// launch gets teams only when all its workgroups fit the context's budget of resident workgroups (and never in the
+// conservative retry mode); results do not depend on the team size (kb_team.hpp).
+int panel_team_size(const kbdm_plan* pl, const Chunk& ch) {
+    const kbdm_ctx* ctx = pl->ctx;
+    if (pl->mode & KBDM_MODE_SOLO_QR) return 1;
+    if (ch.lane != 0 && !ctx->panel_T_all) return 1;
+    int T = std::max(1, ctx->panel_T);
+    while (T > 1 && (long long)((ch.count + 7) / 8 * 8) * T > ctx->panel_budget) --T;
+    return T;
+}
+// rows of the row-product partial sums that fit the LDS next to the other scratch (a multiple of 64; 0: nothing fits)
+int panel_team_zr(int n, int nt) {
+    const int fixed = KB_RED_BYTES + panel_team_scratch_bytes(n, 0, nt);
+    int zr = (LDS_MAX - fixed) / (KB_TEAM_NCG * (int)sizeof(cd)) / 64 * 64;
+    return std::min(zr, (n + 63) / 64 * 64);            // (all the rows in one batch when they fit)
+}
 
 // Explicit unitary factors of a chunk: members with n >= KB_WY_MIN by blocked compact-WY accumulation on FP64 MFMA
 // (the T factors of all blocks in one launch, then one launch per block of 64 reflectors, last block first), the smaller
@@ -364,6 +428,7 @@ int launch_gen(kbdm_plan* pl, Chunk& ch, int nmax, int mode, int nmat, hipStream
         for (int s = 0; s < nblk; ++s) {
             // a member's trailing matrix at step s has at most (s + 1) 64 + 2 rows (its last block is the partial one)
             const int span = std::min(nmax, (s + 2) * KB_WYB);
+            KBracket kb(pl, ch, KBDM_K_WY_APPLY, gst, 1);
             hipLaunchKernelGGL(k_wy_apply, dim3((span + 63) / 64, ch.count, nmat), dim3(256), KB_WY_APPLY_LDS, gst, pl->d_items, perm,
                                pl->d_arena, pl->d_varena, mode, s);
         }
@@ -462,18 +527,35 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         // one-pass panels (bidiag_panel_fused): a column in 8 register chunks and nwaves row accumulators in LDS
         const int smf = KB_RED_BYTES + bidiag_panel_fused_scratch_bytes(ch.mmax, KB_PANEL_FUSED_NT / 64);
         const int fused = (ctx->bidiag_fused && ch.mmax <= KB_PANEL_FUSED_MAXC * 64 && smf <= LDS_MAX) ? 1 : 0;
-        if (npan > 0 && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
+        if (npan > 0 && ctx->panel_old && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
+        const int oldp = ctx->panel_old;
+        const int T = panel_team_size(pl, ch);
+        const int zr = panel_team_zr(ch.mmax, ctx->nt_fac);
+        const int smt = KB_RED_BYTES + panel_team_scratch_bytes(ch.mmax, zr, ctx->nt_fac);
+        if (npan > 0 && !fused && !oldp) {
+            if (zr < 64) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
+            HIPCHK(hipMemsetAsync(pl->d_pteam + ch.first, 0, sizeof(PanelTeamCtl) * ch.count, st));
+        }
         for (int pnl = 0; pnl < npan; ++pnl) {
             if (fused)
                 hipLaunchKernelGGL(k_bidiag_panel<1>, dim3(ch.count), dim3(KB_PANEL_FUSED_NT), smf, st, pl->d_items, perm,
                                    pl->d_arena, pl->d_varena, pnl, smf);
-            else
+            else if (oldp)
                 hipLaunchKernelGGL(k_bidiag_panel<0>, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
                                    pl->d_arena, pl->d_varena, pnl, smp);
+            else {
+                KBracket kb(pl, ch, KBDM_K_BIDIAG_PANEL, st, 1);
+                hipLaunchKernelGGL(k_bidiag_panel_team, dim3((ch.count + 7) / 8 * 8 * T), dim3(ctx->nt_fac), smt, st, pl->d_items,
+                                   perm, pl->d_arena, pl->d_varena, pnl, smt, T, ch.count, pl->d_pteam + ch.first, zr,
+                                   pl->d_status);
+            }
             const int nn = ch.mmax - (pnl + 1) * KB_NB;
             const int tiles = (nn + 63) / 64;
-            hipLaunchKernelGGL(k_trail_update, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
-                               pl->d_arena, pnl);
+            {
+                KBracket kb(pl, ch, KBDM_K_TRAIL_UPDATE, st, 1);
+                hipLaunchKernelGGL(k_trail_update, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
+                                   pl->d_arena, pnl);
+            }
         }
         const int sm = smem_fac(ch.mmax, ctx->nt_fac);
         if (sm > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the bidiagonalisation scratch");
@@ -492,14 +574,35 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     {
         const int npan = ctx->blocked ? bidiag_num_panels(ch.lmax) : 0;
         const int smp = KB_RED_BYTES + hess_panel_scratch_bytes(ch.lmax, ctx->nt_fac / 64, 64);
-        if (npan > 0 && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg panel scratch");
+        if (npan > 0 && ctx->panel_old && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg panel scratch");
+        const int oldp = ctx->panel_old;
+        const int T = panel_team_size(pl, ch);
+        const int zr = panel_team_zr(ch.lmax, ctx->nt_fac);
+        const int smt = KB_RED_BYTES + panel_team_scratch_bytes(ch.lmax, zr, ctx->nt_fac);
+        if (npan > 0 && !oldp) {
+            if (zr < 64) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg panel scratch");
+            HIPCHK(hipMemsetAsync(pl->d_pteam + ch.first, 0, sizeof(PanelTeamCtl) * ch.count, st));
+        }
         for (int pnl = 0; pnl < npan; ++pnl) {
-            hipLaunchKernelGGL(k_hess_panel, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
-                               pl->d_arena, pl->d_varena, pnl, smp);
+            if (oldp)
+                hipLaunchKernelGGL(k_hess_panel, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
+                                   pl->d_arena, pl->d_varena, pnl, smp);
+            else {
+                KBracket kb(pl, ch, KBDM_K_HESS_PANEL, st, 1);
+                hipLaunchKernelGGL(k_hess_panel_team, dim3((ch.count + 7) / 8 * 8 * T), dim3(ctx->nt_fac), smt, st, pl->d_items,
+                                   perm, pl->d_arena, pl->d_varena, pnl, smt, T, ch.count, pl->d_pteam + ch.first, zr,
+                                   pl->d_status);
+            }
             const int ncol = ch.lmax - (pnl + 1) * KB_NB;
-            hipLaunchKernelGGL(k_hess_z, dim3((ncol + 63) / 64, ch.count), dim3(256), 0, st, pl->d_items, perm, pl->d_arena, pnl);
-            hipLaunchKernelGGL(k_hess_update, dim3((ch.lmax + 63) / 64, (ncol + 63) / 64, ch.count), dim3(256), 0, st,
-                               pl->d_items, perm, pl->d_arena, pnl);
+            {
+                KBracket kb(pl, ch, KBDM_K_HESS_Z, st, 1);
+                hipLaunchKernelGGL(k_hess_z, dim3((ncol + 63) / 64, ch.count), dim3(256), 0, st, pl->d_items, perm, pl->d_arena, pnl);
+            }
+            {
+                KBracket kb(pl, ch, KBDM_K_HESS_UPDATE, st, 1);
+                hipLaunchKernelGGL(k_hess_update, dim3((ch.lmax + 63) / 64, (ncol + 63) / 64, ch.count), dim3(256), 0, st,
+                                   pl->d_items, perm, pl->d_arena, pnl);
+            }
         }
         const int sm = KB_RED_BYTES + gehd2_scratch_bytes(ch.lmax, ctx->nt_fac / 64, 64);
         if (sm > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg scratch");
@@ -555,10 +658,15 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             const int sml = KB_RED_BYTES;
             hipLaunchKernelGGL(k_ab_leaf, dim3(1 << Dmax, ch.count), dim3(64), sml, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
                                pl->d_dc, pl->d_needqr, sml);
-            for (int s2 = 0; s2 < Dmax; ++s2)
-                for (int itn = 0; itn < (s2 < Dmin - 1 ? KB_AB_INNER_BUDGET : KB_AB_BUDGET); ++itn)
-                    hipLaunchKernelGGL(k_ab_iter, dim3(gx[s2], ch.count), dim3(256), sizeof(AbLds), st, pl->d_items, perm, pl->d_arena,
-                                       pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn, pl->d_abstat, env_int("KBDM_AB_DBG", 0));
+            {
+                int nlaunch = 0;
+                for (int s2 = 0; s2 < Dmax; ++s2) nlaunch += (s2 < Dmin - 1 ? KB_AB_INNER_BUDGET : KB_AB_BUDGET);
+                KBracket kb(pl, ch, KBDM_K_AB_ITER, st, nlaunch);
+                for (int s2 = 0; s2 < Dmax; ++s2)
+                    for (int itn = 0; itn < (s2 < Dmin - 1 ? KB_AB_INNER_BUDGET : KB_AB_BUDGET); ++itn)
+                        hipLaunchKernelGGL(k_ab_iter, dim3(gx[s2], ch.count), dim3(256), sizeof(AbLds), st, pl->d_items, perm, pl->d_arena,
+                                           pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn, pl->d_abstat, ctx->ab_dbg);
+            }
             hipLaunchKernelGGL(k_ab_finish, dim3(ch.count), dim3(256), KB_RED_BYTES, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
                                pl->d_dc, pl->d_mu, pl->d_needqr);
         }
@@ -672,8 +780,11 @@ int run_chunk(kbdm_plan* pl, Chunk& ch) {
         HankelOut o0{pl->d_arena, pl->p - 1, KB_BUF_A, 1};
         HankelOut none{nullptr, 0, 0, 0};
         const int tiles = (ch.mmax + HK_TILE - 1) / HK_TILE;
-        hipLaunchKernelGGL(k_hankel, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
-                           pl->d_signals, pl->N, 1, o0, none, none);
+        {
+            KBracket kb(pl, ch, KBDM_K_HANKEL, st, 1);
+            hipLaunchKernelGGL(k_hankel, dim3(tiles, tiles, ch.count), dim3(256), 0, st, pl->d_items, perm,
+                               pl->d_signals, pl->N, 1, o0, none, none);
+        }
         if ((r = tm.mark())) return r;
     }
     if ((r = launch_svd(pl, ch, &tm))) return r;
@@ -698,6 +809,26 @@ int run_chunk(kbdm_plan* pl, Chunk& ch) {
     HIPCHK(hipGetLastError());
     return KBDM_OK;
 }
+
+// Trailer of a packed block: the sender's rank and the sequence number of the gather it belongs to.  The ranks must issue
+// the gathers of all their contexts in the same order (they share one communicator); a slip would deliver a block of ANOTHER
+// step without any error from the transport - the receiver's check turns it into an error instead.
+constexpr unsigned KB_TRAILER_MAGIC = 0x4B42444Du;        // "KBDM"
+struct KbTrailer { unsigned magic, rank; unsigned long long seq; };
+__global__ void k_write_trailer(char* block_end, unsigned rank, unsigned long long seq) {
+    KbTrailer t{KB_TRAILER_MAGIC, rank, seq};
+    *reinterpret_cast<KbTrailer*>(block_end - sizeof(KbTrailer)) = t;
+}
+constexpr int KB_TRAILER_MAX_WORLD = 64;
+struct KbBlockOffs { long long o[KB_TRAILER_MAX_WORLD + 1]; };
+__global__ void k_check_trailers(const char* gathered, KbBlockOffs offs, int world, unsigned long long seq, int* bad) {
+    const long long* off = offs.o;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= world || off[r + 1] == off[r]) return;
+    const KbTrailer t = *reinterpret_cast<const KbTrailer*>(gathered + off[r + 1] - sizeof(KbTrailer));
+    if (t.magic != KB_TRAILER_MAGIC || t.rank != (unsigned)r || t.seq != seq) atomicOr(bad, 1);
+}
+std::atomic<unsigned long long> g_gather_seq{0};           // one communicator per process: one sequence
 
 }  // namespace
 
@@ -758,6 +889,14 @@ int kbdm_ctx_create_lanes(int device, int nlanes, kbdm_ctx** out) {
     c->eig_ab = env_int("KBDM_EIG_AB", c->eig_ab);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
     c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
+    c->panel_T = std::min(32, std::max(1, env_int("KBDM_PANEL_T", c->panel_T)));
+    c->panel_budget = std::max(8, env_int("KBDM_PANEL_BUDGET", c->panel_budget));
+    c->panel_T_all = env_int("KBDM_PANEL_T_ALL", c->panel_T_all);
+    c->panel_old = env_int("KBDM_PANEL_OLD", c->panel_old);
+    c->ab_dbg = env_int("KBDM_AB_DBG", 0);
+#if !defined(KBDM_DEBUG_BUILD)
+    c->ab_dbg &= ~(2 | 4);
+#endif
     c->nb_hqr2 = std::min(KB2_NBMAX, std::max(1, env_int("KBDM_NB_HQR2", c->nb_hqr2)));
     c->win_hqr2 = KB2_WIN_DEV;                       // the device chase is compiled for this window
     c->split_gen = std::max(1, env_int("KBDM_SPLIT_GEN", c->split_gen));
@@ -776,23 +915,36 @@ int kbdm_ctx_create_lanes(int device, int nlanes, kbdm_ctx** out) {
     return KBDM_OK;
 }
 
+int kbdm_ctx_set_panel_teams(kbdm_ctx* ctx, int T, int budget, int all_lanes, double lane0_frac) {
+    if (!ctx || T < 1 || T > 32 || budget < 8) return fail(KBDM_E_INVALID, "bad panel-team policy");
+    ctx->panel_T = T;
+    ctx->panel_budget = budget;
+    ctx->panel_T_all = all_lanes ? 1 : 0;
+    if (lane0_frac > 0.0) ctx->lane0_frac = std::min(0.95, std::max(0.05, lane0_frac));
+    return KBDM_OK;
+}
+
 int kbdm_ctx_destroy(kbdm_ctx* ctx) {
     if (!ctx) return KBDM_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->comm) kbdm_comm_destroy(ctx);          // (synchronises the streams it used: before any of them is destroyed)
+    if (ctx->comm_stream) { hipStreamSynchronize(ctx->comm_stream); hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
     for (int i = 0; i < KB_MAX_LANES; ++i) {
         Lane& ln = ctx->lanes[i];
         if (ln.stream2 && ln.stream2 != ln.stream) hipStreamDestroy(ln.stream2);
         if (ln.stream) hipStreamDestroy(ln.stream);
+        ln.stream = ln.stream2 = nullptr;
         if (ln.ev_fork) hipEventDestroy(ln.ev_fork);
         if (ln.ev_join) hipEventDestroy(ln.ev_join);
         if (ln.ev_done) hipEventDestroy(ln.ev_done);
     }
+    ctx->stream = nullptr;
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
-    if (ctx->comm_stream) { hipStreamSynchronize(ctx->comm_stream); hipStreamDestroy(ctx->comm_stream); }
     if (ctx->ev_packed) hipEventDestroy(ctx->ev_packed);
     if (ctx->ev_gathered) hipEventDestroy(ctx->ev_gathered);
-    if (ctx->comm) kbdm_comm_destroy(ctx);
     if (ctx->d_pack) hipFree(ctx->d_pack);
     if (ctx->d_gather) hipFree(ctx->d_gather);
+    if (ctx->d_gather_bad) hipFree(ctx->d_gather_bad);
     delete ctx;
     return KBDM_OK;
 }
@@ -815,7 +967,7 @@ int kbdm_plan_destroy(kbdm_plan* pl) {
     hipFree(pl->d_signals); hipFree(pl->d_items); hipFree(pl->d_perm); hipFree(pl->d_arena);
     hipFree(pl->d_varena); hipFree(pl->d_lines); hipFree(pl->d_sv); hipFree(pl->d_mu);
     hipFree(pl->d_keep); hipFree(pl->d_status); hipFree(pl->d_iwork);
-    hipFree(pl->d_team); hipFree(pl->d_rings); hipFree(pl->d_dc); hipFree(pl->d_needqr); hipFree(pl->d_abstat);
+    hipFree(pl->d_team); hipFree(pl->d_pteam); hipFree(pl->d_rings); hipFree(pl->d_dc); hipFree(pl->d_needqr); hipFree(pl->d_abstat);
     if (pl->h_signals) hipHostFree(pl->h_signals);
     if (pl->h_out) hipHostFree(pl->h_out);
     for (auto& ch : pl->chunks)
@@ -910,6 +1062,29 @@ int kbdm_plan_stage_ms(kbdm_plan* pl, float* ms, int n) {
     return KBDM_OK;
 }
 
+const char* kbdm_kernel_class_name(int k) { return (k >= 0 && k < KBDM_NKCLASSES) ? kKernelClassNames[k] : nullptr; }
+
+int kbdm_plan_kernel_ms(kbdm_plan* pl, int k, float* total_ms, int32_t* launches) {
+    if (!pl || !total_ms || !launches || k < 0 || k >= KBDM_NKCLASSES) return fail(KBDM_E_INVALID, "bad kernel class");
+    for (int i = 0; i < pl->ctx->nlanes; ++i)
+        if (pl->ctx->lanes[i].stream) HIPCHK(hipStreamSynchronize(pl->ctx->lanes[i].stream));
+    if (pl->ctx->lanes[0].stream2) HIPCHK(hipStreamSynchronize(pl->ctx->lanes[0].stream2));
+    float tot = 0.f;
+    int n = 0;
+    for (auto& ch : pl->chunks) {
+        if (ch.lane != 0) continue;                 // lane 0 holds the largest members: the launches the stage timers cover
+        for (int e = 0; e + 1 < ch.kused[k]; e += 2) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, ch.kev[k][e], ch.kev[k][e + 1]));
+            tot += t;
+        }
+        n += ch.klaunches[k];
+    }
+    *total_ms = tot;
+    *launches = n;
+    return KBDM_OK;
+}
+
 int kbdm_plan_eig_fallbacks(kbdm_plan* pl) {
     if (!pl || pl->B == 0) return 0;
     std::vector<int> h(pl->B);
@@ -949,14 +1124,30 @@ int kbdm_plan_download(kbdm_plan* pl, double* lines, double* sv, double* mu, uin
     if (status && pl->B) HIPCHK(hipMemcpyAsync(status, pl->d_status, sizeof(int) * pl->B, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (status) {
-        const int force = env_int("KBDM_DEBUG_FORCE_STATUS", 0);      // test hook: pretend the members failed
+        const int force = g_force_status.load();                      // test hook: pretend the members failed
         if (force) for (int i = 0; i < pl->B; ++i) status[i] |= force;
     }
     return KBDM_OK;
 }
 
+int kbdm_debug_force_status(int always, int once) {
+    g_force_status.store(always);
+    g_force_status_once.store(once);
+    return KBDM_OK;
+}
+
+#if defined(KB_PANEL_PROF)
+// diagnostic builds only (tools/panel_phases.py): device address of a __device__ symbol of this library
+int kbdm_debug_symbol(const char* name, void** ptr, size_t* bytes) {
+    if (strcmp(name, "kb_panel_prof") != 0) return KBDM_E_INVALID;
+    HIPCHK(hipGetSymbolAddress(ptr, HIP_SYMBOL(kb_panel_prof)));
+    HIPCHK(hipGetSymbolSize(bytes, HIP_SYMBOL(kb_panel_prof)));
+    return KBDM_OK;
+}
+#endif
+
 int kbdm_plan_set_mode(kbdm_plan* pl, int mode) {
-    if (!pl || (mode & ~KBDM_MODE_SOLO_QR)) return fail(KBDM_E_INVALID, "bad mode");
+    if (!pl || (mode & ~(KBDM_MODE_SOLO_QR | KBDM_MODE_KERNEL_TIMERS))) return fail(KBDM_E_INVALID, "bad mode");
     pl->mode = mode;
     return KBDM_OK;
 }
@@ -1039,11 +1230,7 @@ int kbdm_plan_collect(kbdm_plan* pl, double* lines, double* sv, double* mu, uint
     if (keep) memcpy(keep, h + o.keep, (size_t)pl->total_lines);
     if (status) {
         memcpy(status, h + o.status, 4 * (size_t)pl->B);
-        int force = env_int("KBDM_DEBUG_FORCE_STATUS", 0);            // test hooks: pretend the members failed
-        if (const int once = env_int("KBDM_DEBUG_FORCE_STATUS_ONCE", 0)) {     // ... in the next collected run only
-            force |= once;
-            unsetenv("KBDM_DEBUG_FORCE_STATUS_ONCE");
-        }
+        const int force = g_force_status.load() | g_force_status_once.exchange(0);   // test hooks: pretend the members failed
         if (force) for (int i = 0; i < pl->B; ++i) status[i] |= force;
     }
     return KBDM_OK;
@@ -1157,7 +1344,7 @@ int kbdm_comm_destroy(kbdm_ctx* ctx) {
 
 int64_t kbdm_packed_bytes(int64_t lines, int64_t sv, int64_t members) {
     const int64_t raw = 32 * lines + 8 * sv + 4 * members + lines;
-    return (raw + 15) & ~(int64_t)15;
+    return ((raw + 15) & ~(int64_t)15) + 16;        // + the trailer {magic, rank, sequence number of the gather}
 }
 
 void* kbdm_gathered_device(kbdm_ctx* ctx) { return ctx ? ctx->d_gather : nullptr; }
@@ -1197,7 +1384,14 @@ int kbdm_plan_gather(kbdm_plan* pl, int world, int rank, const int64_t* bytes, i
     hipStream_t cs = ctx->comm_stream;
     if (ctx->gather_pending) HIPCHK(hipStreamWaitEvent(st, ctx->ev_gathered, 0));
     char* d = ctx->d_pack;
-    if (mine > 0) HIPCHK(hipMemsetAsync(d + (mine - 16), 0, 16, st));     // the padding bytes are defined
+    if (mine >= 32) HIPCHK(hipMemsetAsync(d + (mine - 32), 0, 16, st));   // the padding bytes are defined
+    const unsigned long long seq = ++g_gather_seq;
+    hipLaunchKernelGGL(k_write_trailer, dim3(1), dim3(1), 0, st, d + mine, (unsigned)rank, seq);
+    if (!ctx->d_gather_bad) {
+        HIPCHK(hipMalloc(&ctx->d_gather_bad, sizeof(int)));
+        HIPCHK(hipMemset(ctx->d_gather_bad, 0, sizeof(int)));
+    }
+
     if (pl->total_lines) HIPCHK(hipMemcpyAsync(d, pl->d_lines, 32 * pl->total_lines, hipMemcpyDeviceToDevice, st));
     d += 32 * pl->total_lines;
     if (pl->total_sv) HIPCHK(hipMemcpyAsync(d, pl->d_sv, 8 * pl->total_sv, hipMemcpyDeviceToDevice, st));
@@ -1224,17 +1418,46 @@ int kbdm_plan_gather(kbdm_plan* pl, int world, int rank, const int64_t* bytes, i
         NCCLCHK(err);
         NCCLCHK(end);
     }
+    if (receive && total && world <= KB_TRAILER_MAX_WORLD) {
+        // every block that arrived carries its sender's rank and THIS gather's sequence number
+        KbBlockOffs offs;
+        for (int r = 0; r <= world; ++r) offs.o[r] = off[r];
+        hipLaunchKernelGGL(k_check_trailers, dim3(1), dim3(KB_TRAILER_MAX_WORLD), 0, cs, ctx->d_gather, offs, world, seq, ctx->d_gather_bad);
+    }
     if (host_out && receive && total) HIPCHK(hipMemcpyAsync(host_out, ctx->d_gather, total, hipMemcpyDeviceToHost, cs));
     HIPCHK(hipEventRecord(ctx->ev_gathered, cs));
     ctx->gather_pending = true;
-    if (host_out) HIPCHK(hipStreamSynchronize(cs));          // a host copy was asked for: the call completes it
+    if (host_out) return kbdm_gather_wait(ctx);              // a host copy was asked for: the call completes it
     return KBDM_OK;
 }
 
 int kbdm_gather_wait(kbdm_ctx* ctx) {
     if (!ctx) return fail(KBDM_E_INVALID, "null context");
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->comm_stream) HIPCHK(hipStreamSynchronize(ctx->comm_stream));
+    if (!ctx->comm_stream || !ctx->gather_pending) return KBDM_OK;
+    // Bounded: a rank that has died leaves its peers inside the grouped transfer for good.  Poll the event that closes the
+    // gather and give up after KBDM_GATHER_TIMEOUT_S (default 300 s): the caller gets an error, the process exits with a
+    // non-zero code and the launcher (llckbdm_amd.launch.spawn) tears the other ranks down.
+    const double limit = std::max(1, env_int("KBDM_GATHER_TIMEOUT_S", 300));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ctx->ev_gathered);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); return fail(KBDM_E_HIP, "the gather failed on the device"); }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            return fail(KBDM_E_HIP, "kbdm_gather_wait: the gather did not finish within KBDM_GATHER_TIMEOUT_S (a peer rank is gone?)");
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    (void)hipGetLastError();
+    if (ctx->d_gather_bad) {
+        int bad = 0;
+        HIPCHK(hipMemcpy(&bad, ctx->d_gather_bad, sizeof(int), hipMemcpyDeviceToHost));
+        if (bad) {
+            HIPCHK(hipMemset(ctx->d_gather_bad, 0, sizeof(int)));
+            return fail(KBDM_E_HIP, "gather: a received block carries another step's sequence number or another rank's id "
+                                    "(the ranks did not issue their gathers in the same order)");
+        }
+    }
     return KBDM_OK;
 }
 

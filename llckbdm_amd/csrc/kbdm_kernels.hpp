@@ -25,6 +25,7 @@
 #include "kb_hqr_ms.hpp"
 #include "kb_hqr2.hpp"
 #include "kb_svd.hpp"
+#include "kb_panel_team.hpp"
 #include "kbdm_device.h"
 
 using namespace kb;
@@ -102,6 +103,50 @@ __global__ void __launch_bounds__(FUSED ? KB_PANEL_FUSED_NT : 1024) k_bidiag_pan
     // and sizes the scratch for it)
     if (FUSED) bidiag_panel_fused<DevCtx, KB_PANEL_FUSED_MAXC>(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
     else bidiag_panel(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
+}
+
+// The panel for a team of T workgroups per member (kb_team.hpp, kb_panel_team.hpp; T = 1: one workgroup, no waiting).
+// grid = 8 * ceil(count / 8) * T: block b belongs to slot b & 7 (blocks of equal slot share an XCD when the dispatcher deals
+// them round robin - faster, never required), within the slot consecutive groups of T blocks are the teams.  `pos0` is the
+// chunk's first position in the sorted order (the control words are indexed by position), `epoch0` the synchronisations
+// a team has behind it when this launch starts (every panel of a stage makes the same number).
+__device__ __forceinline__ bool team_geom(int T, int count, int& team, int& role) {
+    const int b = blockIdx.x;
+    const int idx = b >> 3;
+    role = idx % T;
+    team = (idx / T) * 8 + (b & 7);
+    return team < count;
+}
+constexpr int KB_BIDIAG_TEAM_SYNCS = 2 * KB_NB + 1;     // per panel
+constexpr int KB_HESS_TEAM_SYNCS = KB_NB + 1;
+
+__global__ void __launch_bounds__(1024) k_bidiag_panel_team(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                             cd* arena, double* varena, int panel, int smem_bytes, int T,
+                                                             int count, PanelTeamCtl* ctl, int zr, int* status) {
+    int team, role;
+    if (!team_geom(T, count, team, role)) return;
+    const int item = perm[team];
+    const KbItem it = items[item];
+    const int m = it.m;
+    if (panel >= bidiag_num_panels(m)) return;
+    const DevCtx ctx = make_ctx(smem_bytes);
+    PanelTeam<DevCtx> tm;
+    tm.T = T; tm.role = role; tm.ctl = ctl + team; tm.failed = 0;
+    tm.epoch = (unsigned)(panel * KB_BIDIAG_TEAM_SYNCS);
+    tm.xb = arena + it.off[KB_BUF_H];                      // free until the unitary factors are accumulated
+    if (T > 1 && __hip_atomic_load(&tm.ctl->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const int p0 = panel * KB_NB;
+    cd* A = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;
+    cd* UR = arena + it.off[KB_BUF_R] + p0 + (size_t)p0 * m;
+    cd* X = arena + it.off[KB_BUF_Q];
+    cd* Y = arena + it.off[KB_BUF_P];
+    double* dv = varena + it.voff;
+    double* d = dv + KB_V_D * it.vstride + p0;
+    double* e = dv + KB_V_E * it.vstride + p0;
+    cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride) + p0;
+    cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride) + p0;
+    if (!bidiag_panel_team(ctx, tm, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m, zr) && threadIdx.x == 0)
+        atomicOr(&status[item], KB_STAT_SVD_NOCONV);
 }
 
 // Rank-64 update of one 64 x 64 tile of C on FP64 MFMA:  C[r, c] -= sum_k Aop(r, k) conj(Bop(c, k)), k < 2 NB.
@@ -575,6 +620,31 @@ __global__ void __launch_bounds__(1024) k_hess_panel(const KbItem* __restrict__ 
     cd* Z = arena + it.off[KB_BUF_H];          // Z (n x NB), then MT (NB x NB), then VT (n x NB): n >= NB + NX
     cd* tauh = reinterpret_cast<cd*>(varena + it.voff + KB_V_TAUQ * it.vstride) + p0;
     hess_panel(ctx, n, W, n, p0, tauh, Y, n, Z + (size_t)n * KB_NB + KB_NB * KB_NB, n, Z + (size_t)n * KB_NB);
+}
+
+__global__ void __launch_bounds__(1024) k_hess_panel_team(const KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                           cd* arena, double* varena, int panel, int smem_bytes, int T,
+                                                           int count, PanelTeamCtl* ctl, int zr, int* status) {
+    int team, role;
+    if (!team_geom(T, count, team, role)) return;
+    const int item = perm[team];
+    const KbItem it = items[item];
+    const int n = it.l;
+    if (panel >= bidiag_num_panels(n)) return;
+    const DevCtx ctx = make_ctx(smem_bytes);
+    PanelTeam<DevCtx> tm;
+    tm.T = T; tm.role = role; tm.ctl = ctl + team; tm.failed = 0;
+    tm.epoch = (unsigned)(panel * KB_HESS_TEAM_SYNCS);
+    tm.xb = arena + it.off[KB_BUF_A];                      // L is dead after k_gemm<2>, B is written by k_gemm<4>
+    if (T > 1 && __hip_atomic_load(&tm.ctl->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const int p0 = panel * KB_NB;
+    cd* W = arena + it.off[KB_BUF_P];
+    cd* Y = arena + it.off[KB_BUF_Q];
+    cd* Z = arena + it.off[KB_BUF_H];          // Z (n x NB), then MT (NB x NB), then VT (n x NB): n >= NB + NX
+    cd* tauh = reinterpret_cast<cd*>(varena + it.voff + KB_V_TAUQ * it.vstride) + p0;
+    if (!hess_panel_team(ctx, tm, n, W, n, p0, tauh, Y, n, Z + (size_t)n * KB_NB + KB_NB * KB_NB, n, Z + (size_t)n * KB_NB, zr) &&
+        threadIdx.x == 0)
+        atomicOr(&status[item], KB_STAT_EIG_NOCONV);
 }
 
 // Deferred left factor of a panel, all CUs:  Z(c, :) = A0(:, c)^H VT - V(c, :) MT  for the columns right of the

@@ -32,14 +32,18 @@ def shard_items(costs, world_size):
     return [np.array(sorted(b), dtype=np.int64) for b in buckets]
 
 
+TRAILER_BYTES = 16
+TRAILER_MAGIC = 0x4B42444D      # "KBDM"
+
+
 def packed_bytes(lines, sv, members):
     """Size of a rank's packed block (include/kbdm_hip.h: kbdm_packed_bytes): lines x 4 f64 | sv f64 | status i32 |
-    keep u8, padded to 16 bytes."""
+    keep u8, padded to 16 bytes, + the 16-byte trailer {u32 magic, u32 rank, u64 gather sequence number}."""
     raw = 32 * int(lines) + 8 * int(sv) + 4 * int(members) + int(lines)
-    return (raw + 15) & ~15
+    return ((raw + 15) & ~15) + TRAILER_BYTES
 
 
-def pack_block(lines, sv, status, keep):
+def pack_block(lines, sv, status, keep, rank=0, seq=0):
     """Host-side packing in the library's layout (used by the gloo stand-in and by tests)."""
     lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 4)
     sv = np.ascontiguousarray(sv, dtype=np.float64).ravel()
@@ -51,7 +55,16 @@ def pack_block(lines, sv, status, keep):
         b = part.view(np.uint8).ravel()
         out[o:o + b.size] = b
         o += b.size
+    out[-TRAILER_BYTES:] = np.frombuffer(np.array([TRAILER_MAGIC, int(rank)], dtype=np.uint32).tobytes() +
+                                         np.array([int(seq)], dtype=np.uint64).tobytes(), dtype=np.uint8)
     return out
+
+
+def block_trailer(buf):
+    """(magic, rank, seq) of a packed block."""
+    t = np.ascontiguousarray(buf, dtype=np.uint8)[-TRAILER_BYTES:]
+    magic, rank = np.frombuffer(t[:8].tobytes(), dtype=np.uint32)
+    return int(magic), int(rank), int(np.frombuffer(t[8:].tobytes(), dtype=np.uint64)[0])
 
 
 def unpack_block(buf, lines, sv, members):

@@ -185,6 +185,18 @@ class Plan:
         names = [self.engine.lib.kbdm_stage_name(i).decode() for i in range(_lib.KBDM_NSTAGES)]
         return dict(zip(names, ms.tolist()))
 
+    def kernel_ms(self):
+        """Per-kernel HIP-event timers of the last run in `_lib.MODE_KERNEL_TIMERS` mode (lane 0's launches):
+        {kernel class: (total ms, launches)}."""
+        lib = self.engine.lib
+        out = {}
+        for k in range(_lib.KBDM_NKCLASSES):
+            ms = np.zeros(1, dtype=np.float32)
+            n = np.zeros(1, dtype=np.int32)
+            _lib.check(lib.kbdm_plan_kernel_ms(self.handle, k, _lib.ptr(ms), _lib.ptr(n)))
+            out[lib.kbdm_kernel_class_name(k).decode()] = (float(ms[0]), int(n[0]))
+        return out
+
     def lane0_members(self):
         """Members (the largest ones) in lane 0, whose stage timers `stage_ms` reports."""
         return int(self.engine.lib.kbdm_plan_lane0_members(self.handle))
@@ -275,12 +287,14 @@ class Engine:
         self.device = int(device) % n
         self.in_flight = max(1, int(os.environ.get("KBDM_IN_FLIGHT", "4") if in_flight is None else in_flight))
         self._lock = threading.RLock()
+        self._wide = None
         self._slots = [_Slot(self._new_ctx())]
         self.ctx = self._slots[0].ctx
         self._seq = 0
         self._burst = 0
         self._last = None
         self.stagger = os.environ.get("KBDM_STAGGER", "1") != "0"
+        self.wide_solve = os.environ.get("KBDM_WIDE_SOLVE", "1") != "0"   # synchronous batches on the context with panel teams
         # Plans of recent batches, keyed on the batch geometry: a plan owns its device workspace (about 1 GB for a C2
         # ensemble, up to the 96 GiB workspace budget for a C4-sized one), and callers such as `sample_kbdm` /
         # `iterative_llc_kbdm` solve the same geometry again and again with new signals.  The cache is bounded by
@@ -298,17 +312,34 @@ class Engine:
         _lib.check(self.lib.kbdm_ctx_create_lanes(self.device, lanes, h))
         return h
 
+    # Cooperative panels (include/kbdm_hip.h: kbdm_ctx_set_panel_teams).  The workgroups of a team wait for each other, so
+    # the contexts that can run at the same time must not ask for more resident workgroups than the GPU has compute units:
+    # the contexts of the in-flight pool run without teams (their panels overlap other ensembles' work instead); ONE
+    # synchronous batch at a time - `solve`: kbdm, sample_kbdm, llc_kbdm - runs on a context of its own with teams of up
+    # to WIDE_T workgroups for its largest members and three lanes.  Same bits either way.
+    WIDE_T, WIDE_BUDGET, WIDE_LANES, WIDE_LANE0_FRAC = 4, 192, 3, 0.6
+
+    def _wide_slot(self):
+        if self._wide is None:
+            h = _lib.c_void_p()
+            _lib.check(self.lib.kbdm_ctx_create_lanes(self.device, int(os.environ.get("KBDM_WIDE_LANES", self.WIDE_LANES)), h))
+            _lib.check(self.lib.kbdm_ctx_set_panel_teams(h, int(os.environ.get("KBDM_WIDE_T", self.WIDE_T)),
+                                                         int(os.environ.get("KBDM_WIDE_BUDGET", self.WIDE_BUDGET)), 0,
+                                                         float(os.environ.get("KBDM_WIDE_LANE0_FRAC", self.WIDE_LANE0_FRAC))))
+            self._wide = _Slot(h)
+        return self._wide
+
     def plan(self, S, N, sig_idx, m, l, p=1, q=0.0, dwell=1.0, ctx=None):
         return Plan(self, S, N, sig_idx, m, l, p, q, dwell, ctx=ctx)
 
     # ---- plan cache -------------------------------------------------------------------
     def _held_bytes(self):
-        return sum(pl.workspace_bytes() for sl in self._slots for pl in sl.plans.values() if pl.handle is not None)
+        return sum(pl.workspace_bytes() for sl in self._all_slots() for pl in sl.plans.values() if pl.handle is not None)
 
     def _evict(self, need, keep_slot=None, everything=False):
         """Close idle cached plans, least recently used first, until `need` more bytes fit the budget."""
         cands = []
-        for sl in self._slots:
+        for sl in self._all_slots():
             busy = sl.pending._plan if sl.pending is not None else None
             for key, pl in sl.plans.items():
                 if pl is not busy:
@@ -357,7 +388,7 @@ class Engine:
     def clear_plan_cache(self):
         with self._lock:
             self.drain()
-            for sl in self._slots:
+            for sl in self._all_slots():
                 for plan in sl.plans.values():
                     plan.close()
                 sl.plans.clear()
@@ -384,7 +415,7 @@ class Engine:
                 self._slots.append(_Slot(self._new_ctx()))
             return [sl.ctx for sl in self._slots]
 
-    def submit(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0, resident=False):
+    def submit(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0, resident=False, _wide=False):
         """Start one batch (host signals in, host results out) and return at once: a `Pending`.  Up to `in_flight`
         batches run concurrently, each on its own context; a further submit first waits for the oldest one.
         `resident`: skip the upload when the plan that takes the batch already holds exactly this `signals` object
@@ -399,7 +430,12 @@ class Engine:
             key = (int(S), int(N), sig_idx.tobytes(), m.tobytes(), l.tobytes(), int(p), float(q), float(dwell))
             if all(sl.pending is None for sl in self._slots):
                 self._burst = 0
-            sl = self._pick_slot(lambda s: key in s.plans and s.plans[key].handle is not None)
+            if self._wide is not None and self._wide.pending is not None:
+                self._wide.pending._finish()              # the wide context never runs beside the pool (resident-team budget)
+            if _wide and all(sl.pending is None for sl in self._slots):
+                sl = self._wide_slot()
+            else:
+                sl = self._pick_slot(lambda s: key in s.plans and s.plans[key].handle is not None)
             plan = self.cached_plan(S, N, sig_idx, m, l, p, q, dwell, slot=sl)
             nfl = self.in_flight
             if self.stagger and 1 <= self._burst < nfl and self._last is not None and self._last._plan is not None \
@@ -421,17 +457,20 @@ class Engine:
             self._burst += 1
             return pend
 
+    def _all_slots(self):
+        return self._slots + ([self._wide] if self._wide is not None else [])
+
     def drain(self):
         """Wait for every batch in flight (their results stay with their `Pending`)."""
         with self._lock:
-            for sl in self._slots:
+            for sl in self._all_slots():
                 if sl.pending is not None:
                     sl.pending._finish()
 
     def solve(self, signals, sig_idx, m, l=None, p=1, q=0.0, dwell=1.0, check=False):
         """signals: (S, N) complex; items (sig_idx[i], m[i], l[i]).  Returns BatchResult (raw status word unless
         `check`).  The plan (device workspace) of a geometry is reused by later calls with the same geometry."""
-        return self.submit(signals, sig_idx, m, l, p, q, dwell).result(check=check)
+        return self.submit(signals, sig_idx, m, l, p, q, dwell, _wide=self.wide_solve).result(check=check)
 
     # ---- stage entry points (parity tests) -------------------------------------------
     def hankel(self, signals, sig_idx, m, p):
@@ -527,9 +566,10 @@ class Engine:
     def close(self):
         if self.ctx is not None:
             self.clear_plan_cache()
-            for sl in self._slots:
+            for sl in self._all_slots():
                 self.lib.kbdm_ctx_destroy(sl.ctx)
             self._slots = []
+            self._wide = None
             self.ctx = None
 
 

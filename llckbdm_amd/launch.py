@@ -7,8 +7,9 @@ on 127.0.0.1 (rank 0 listens); `spawn` starts the ranks as child processes.  It 
 that exports RANK / WORLD_SIZE / MASTER_PORT (e.g. `python -m torch.distributed.run`): the port is derived from
 MASTER_PORT, nothing of that launcher's own machinery is used.
 """
+import hmac
 import os
-import pickle
+import secrets
 import socket
 import struct
 import subprocess
@@ -37,6 +38,26 @@ def _recv(sock):
     return bytes(buf)
 
 
+def _pack_parts(parts):
+    """[bytes] -> count + (length, bytes) pairs: the payloads are opaque byte strings, nothing is ever unpickled."""
+    return struct.pack("<I", len(parts)) + b"".join(struct.pack("<Q", len(b)) + b for b in parts)
+
+
+def _unpack_parts(blob, world):
+    n, = struct.unpack_from("<I", blob, 0)
+    if n != world:
+        raise ConnectionError(f"rendezvous: {n} parts for a world of {world}")
+    out, o = [], 4
+    for _ in range(n):
+        ln, = struct.unpack_from("<Q", blob, o)
+        o += 8
+        if o + ln > len(blob):
+            raise ConnectionError("rendezvous: truncated frame")
+        out.append(blob[o:o + ln])
+        o += ln
+    return out
+
+
 def rendezvous_port():
     """KBDM_RDZV_PORT, or a port next to an external launcher's MASTER_PORT (that port itself belongs to the launcher)."""
     if "KBDM_RDZV_PORT" in os.environ:
@@ -53,6 +74,10 @@ class Rendezvous:
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.port = rendezvous_port() if port is None else int(port)
+        self.timeout = float(timeout)
+        # `spawn` hands every rank a random token through the environment: a local process that does not know it
+        # cannot pose as a rank (the hello of a connecting rank is rank + token)
+        self.token = os.environ.get("KBDM_RDZV_TOKEN", "").encode()
         self.peers, self.sock, self.server = [], None, None
         if self.world == 1:
             return
@@ -65,8 +90,17 @@ class Rendezvous:
             peers = {}
             while len(peers) < self.world - 1:
                 conn, _ = self.server.accept()
+                conn.settimeout(timeout)            # a peer that dies later raises here instead of hanging rank 0
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                r, = struct.unpack("<I", _recv(conn))
+                try:
+                    hello = _recv(conn)
+                    r, = struct.unpack_from("<I", hello, 0)
+                    ok = 1 <= r < self.world and r not in peers and hmac.compare_digest(hello[4:], self.token)
+                except (ConnectionError, OSError, struct.error):
+                    ok = False
+                if not ok:                          # not one of ours (bad rank, duplicate, wrong token): drop it
+                    conn.close()
+                    continue
                 peers[r] = conn
             self.peers = [peers[r] for r in range(1, self.world)]
         else:
@@ -79,8 +113,9 @@ class Rendezvous:
                     if time.time() - t0 > timeout:
                         raise
                     time.sleep(0.05)
+            self.sock.settimeout(timeout)
             self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send(self.sock, struct.pack("<I", self.rank))
+            _send(self.sock, struct.pack("<I", self.rank) + self.token)
 
     def allgather(self, payload):
         payload = bytes(payload)
@@ -88,12 +123,12 @@ class Rendezvous:
             return [payload]
         if self.rank == 0:
             parts = [payload] + [_recv(c) for c in self.peers]
-            blob = pickle.dumps(parts)
+            blob = _pack_parts(parts)
             for c in self.peers:
                 _send(c, blob)
             return parts
         _send(self.sock, payload)
-        return pickle.loads(_recv(self.sock))
+        return _unpack_parts(_recv(self.sock), self.world)
 
     def bcast(self, payload, src=0):
         return self.allgather(payload if self.rank == src else b"")[src]
@@ -118,24 +153,48 @@ class Rendezvous:
         self.peers, self.sock, self.server = [], None, None
 
 
-def spawn(argv, world, env=None, port=None):
+def spawn(argv, world, env=None, port=None, poll=0.05, grace=5.0):
     """Start `world` ranks of `argv` (a command line) as child processes with RANK / LOCAL_RANK / WORLD_SIZE /
-    KBDM_RDZV_PORT set; returns the first non-zero exit code (0 if all succeeded).  Never replaces the calling
-    process."""
+    KBDM_RDZV_PORT / KBDM_RDZV_TOKEN set and watch ALL of them: when one exits with a non-zero code (LinAlgError, a HIP
+    error, out of memory) the others - which may sit in the gather or in a rendezvous receive waiting for it - are
+    terminated, then killed after `grace` seconds, and that code is returned (0 if all succeeded).  Children only: the
+    calling process is never replaced."""
     if port is None:
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
+    token = secrets.token_hex(16)
     procs = []
     for r in range(world):
         e = dict(os.environ if env is None else env)
-        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), KBDM_RDZV_PORT=str(port))
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), KBDM_RDZV_PORT=str(port), KBDM_RDZV_TOKEN=token)
         procs.append(subprocess.Popen(list(argv), env=e))
     rc = 0
-    for p in procs:
-        code = p.wait()
-        rc = rc or code
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = code
+                    break
+            if live and rc == 0:
+                time.sleep(poll)
+    finally:
+        live = [p for p in procs if p.poll() is None]
+        for p in live:                              # exactly the processes started above, by handle
+            p.terminate()
+        t0 = time.time()
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, grace - (time.time() - t0)))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
     return rc
 
 

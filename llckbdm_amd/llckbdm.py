@@ -88,13 +88,14 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None, clusterer="g
     if clusterer == "gpu" and len(transformed_line_list) >= 2:
         fits = [k for k in sweep if k <= len(transformed_line_list)]
         labels_all = {}
-        on_gpu = [k for k in fits if k <= GPU_SWEEP_MAX_K]
-        if on_gpu:
-            got, _ = eng.hdbscan_sweep(transformed_line_list, on_gpu, MIN_CLUSTER_SIZE)
-            labels_all.update(zip(on_gpu, got))
-        for k in fits:                       # (beyond any m_range of BASELINE.json: scikit-learn on the host)
-            if k > GPU_SWEEP_MAX_K:
-                labels_all[k] = _fit_labels(transformed_line_list, k, "sklearn", eng)
+        if fits and max(fits) > GPU_SWEEP_MAX_K:
+            # no silent host path: the product computes on the GPU or says why it cannot
+            raise ValueError(f"llc_kbdm: an m_range of {m_range_size} members sweeps min_samples up to {max(fits)}; the GPU "
+                             f"clusterer holds a sample's nearest-neighbour list in LDS and stops at {GPU_SWEEP_MAX_K}. "
+                             "Pass clusterer='sklearn' (host, scikit-learn) explicitly, or shorten m_range.")
+        if fits:
+            got, _ = eng.hdbscan_sweep(transformed_line_list, fits, MIN_CLUSTER_SIZE)
+            labels_all.update(zip(fits, got))
     for min_samples in sweep:
         logger.debug('HDBSCAN with min_samples = %d', min_samples)
         if clusterer == "gpu" and (labels_all is None or min_samples not in labels_all):

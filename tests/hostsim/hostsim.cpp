@@ -18,6 +18,11 @@
 #include "kb_svd.hpp"
 #include "kb_bdsdc.hpp"
 #include "kb_aberth.hpp"
+#include "kb_panel_team.hpp"
+
+#include <functional>
+#include <pthread.h>
+#include <thread>
 
 using namespace kb;
 typedef std::complex<double> zc;
@@ -31,18 +36,50 @@ static HostCtx make_ctx(std::vector<char>& arena, size_t bytes) {
     return c;
 }
 
+// A team of T one-thread "workgroups" (kb_team.hpp): the T roles run as threads that meet in a pthread barrier; every
+// role has a scratch arena of its own, the matrices and the exchange buffer are shared - what the device does.
+static int hs_team_size() {
+    const char* tz = getenv("HS_PANEL_T");
+    const int T = tz ? atoi(tz) : 1;
+    return T < 1 ? 1 : T;
+}
+static void hs_run_team(int T, size_t scratch_bytes, cd* xbuf, const std::function<void(HostCtx&, PanelTeam<HostCtx>&)>& body) {
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, T);
+    auto role_main = [&](int role) {
+        std::vector<char> arena;
+        HostCtx c = make_ctx(arena, scratch_bytes);
+        PanelTeam<HostCtx> tm;
+        tm.T = T; tm.role = role; tm.epoch = 0; tm.ctl = nullptr; tm.xb = xbuf; tm.failed = 0;
+        tm.barrier = [](void* b) { pthread_barrier_wait(static_cast<pthread_barrier_t*>(b)); };
+        tm.barg = &bar;
+        body(c, tm);
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < T; ++r) th.emplace_back(role_main, r);
+    role_main(0);
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&bar);
+}
+constexpr int HS_ZR = 8;       // rows of the row-product partial sums per batch (host wave size 1: 8 chunks per batch)
+
 // blocked bidiagonalisation exactly as the kernels sequence it: panels + trailing updates + tail
 static void hs_bidiag_blocked(HostCtx& ctx, int m, cd* A, double* d, double* e, cd* tq, cd* tp, cd* UR) {
     const int npan = bidiag_num_panels(m);
-    std::vector<cd> X((size_t)m * KB_NB), Y((size_t)m * KB_NB);
+    std::vector<cd> X((size_t)m * KB_NB), Y((size_t)m * KB_NB), xbuf((size_t)panel_team_xbuf_elems(m));
     for (int p = 0; p < npan; ++p) {
         const int p0 = p * KB_NB, n = m - p0;
         cd* Ab = A + p0 + (size_t)p0 * m;
         cd* Ub = UR + p0 + (size_t)p0 * m;
-        // HS_BIDIAG_FUSED=0: the two-pass panel (what members above 512 rows get on the device)
+        // HS_BIDIAG_FUSED=1: the one-pass panel (a knob on the device); HS_BIDIAG_FUSED=0: the round-3 two-pass panel;
+        // default: the team panel the device runs (HS_PANEL_T workgroups per member)
         const char* fz = getenv("HS_BIDIAG_FUSED");
         if (fz && atoi(fz) == 0) bidiag_panel(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
-        else bidiag_panel_fused<HostCtx, HS_MAXC>(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
+        else if (fz) bidiag_panel_fused<HostCtx, HS_MAXC>(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
+        else
+            hs_run_team(hs_team_size(), panel_team_scratch_bytes(n, HS_ZR, 1), xbuf.data(), [&](HostCtx& c, PanelTeam<HostCtx>& tm) {
+                bidiag_panel_team(c, tm, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m, HS_ZR);
+            });
         for (int c = KB_NB; c < n; ++c)
             for (int r = KB_NB; r < n; ++r) {
                 cd acc = Ab[r + (size_t)c * m];
@@ -153,7 +190,13 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
         std::vector<cd> Yp((size_t)n * KB_NB), Zp((size_t)n * KB_NB), VTp((size_t)n * KB_NB), MTp(KB_NB * KB_NB);
         for (int pnl = 0; pnl < npan; ++pnl) {
             const int p0 = pnl * KB_NB;
-            hess_panel(ctx, n, W.data(), n, p0, th.data() + p0, Yp.data(), n, VTp.data(), n, MTp.data());
+            if (getenv("HS_HESS_OLD")) hess_panel(ctx, n, W.data(), n, p0, th.data() + p0, Yp.data(), n, VTp.data(), n, MTp.data());
+            else {
+                std::vector<cd> xbuf((size_t)panel_team_xbuf_elems(n));
+                hs_run_team(hs_team_size(), panel_team_scratch_bytes(n, HS_ZR, 1), xbuf.data(), [&](HostCtx& c, PanelTeam<HostCtx>& tm) {
+                    hess_panel_team(c, tm, n, W.data(), n, p0, th.data() + p0, Yp.data(), n, VTp.data(), n, MTp.data(), HS_ZR);
+                });
+            }
             hess_z_block(ctx, n, W.data(), n, p0, VTp.data(), n, MTp.data(), Zp.data(), n, p0 + KB_NB, n);
             for (int c = p0 + KB_NB; c < n; ++c)
                 for (int r = 0; r < n; ++r) {

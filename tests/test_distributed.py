@@ -4,11 +4,15 @@ The per-rank solver is injected: here it is the oracle (test infrastructure), on
 it is the HIP engine."""
 import os
 import socket
+import sys
+import time
 
 import numpy as np
 import pytest
 
 from llckbdm_amd.distributed import shard_items
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_items_balanced_and_complete():
@@ -19,6 +23,43 @@ def test_shard_items_balanced_and_complete():
     loads = np.array([(ms[p].astype(float) ** 3).sum() for p in parts])
     assert loads.max() / loads.mean() < 1.02
     assert shard_items([5.0], 4)[0].tolist() == [0] and all(len(x) == 0 for x in shard_items([5.0], 4)[1:])
+
+
+@pytest.mark.parametrize("cfg", ["C4", "C5"])
+def test_shard_tables_of_the_full_multi_gpu_configs_at_world_8(cfg):
+    """BASELINE.json configs[3] and [4] at their FULL item lists over 8 ranks (no solve): every item dealt exactly once, the
+    sum of m^3 balanced to 2 %, and the packed-block table every rank derives on its own - sizes, 16-byte alignment and
+    offsets of the gathered buffer - consistent with the per-rank line / singular-value counts."""
+    from llckbdm_amd import datasets
+    from llckbdm_amd.distributed import packed_bytes
+    if cfg == "C4":
+        ms = np.arange(200, 1201, dtype=np.int64)
+        sidx = np.zeros(len(ms), dtype=np.int64)
+    else:
+        mm = np.arange(128, 384, dtype=np.int64)
+        ms = np.tile(mm, 64)
+        sidx = np.repeat(np.arange(64), len(mm))
+    assert len(ms) == (1001 if cfg == "C4" else 16384)
+    world = 8
+    parts = shard_items(ms.astype(np.float64) ** 3, world)
+    again = shard_items(ms.astype(np.float64) ** 3, world)
+    assert all(np.array_equal(a, b) for a, b in zip(parts, again))                      # deterministic: no size exchange needed
+    allidx = np.sort(np.concatenate(parts))
+    assert np.array_equal(allidx, np.arange(len(ms)))                                   # every item exactly once
+    loads = np.array([(ms[p].astype(np.float64) ** 3).sum() for p in parts])
+    assert loads.max() / loads.mean() <= 1.02, loads.max() / loads.mean()
+    sizes = np.array([packed_bytes(ms[p].sum(), ms[p].sum(), len(p)) for p in parts], dtype=np.int64)
+    assert (sizes % 16 == 0).all() and (sizes > 0).all()
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    for r, p in enumerate(parts):
+        L = int(ms[p].sum())
+        raw = 32 * L + 8 * L + 4 * len(p) + L
+        assert raw + 16 <= sizes[r] < raw + 32 and offs[r] % 16 == 0                     # + the 16-byte trailer
+        assert np.all(np.diff(p) > 0)                                                    # a rank keeps the caller's order
+        assert len(np.unique(sidx[p])) >= 1
+    assert offs[-1] == sizes.sum()
+    total = 41 * int(ms.sum()) + 4 * len(ms) + 16 * world
+    assert total <= offs[-1] < total + 16 * world
 
 
 class _OracleResult:
@@ -162,6 +203,68 @@ def test_rendezvous_primitives_world3():
         assert out[r] == ([b"\x00", b"\x01\x01", b"\x02\x02\x02"], b"id-from-1", 3.0, b"x" * 128)
 
 
+def test_rendezvous_drops_a_stranger_and_frames_are_plain_bytes(monkeypatch):
+    """A local process that connects without the launch token (or with a bad / duplicate rank) is dropped, the real
+    ranks still meet; payloads travel as length-prefixed byte strings (nothing is unpickled)."""
+    import struct
+    import threading
+    from llckbdm_amd import launch
+    monkeypatch.setenv("KBDM_RDZV_TOKEN", "s3cret")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = {}
+
+    def run(r):
+        rz = launch.Rendezvous(r, 2, port, timeout=30)
+        try:
+            out[r] = rz.allgather(b"payload-%d" % r)
+        finally:
+            rz.close()
+    t0 = threading.Thread(target=run, args=(0,))
+    t0.start()
+    for hello in (struct.pack("<I", 1) + b"wrong", struct.pack("<I", 7) + b"s3cret", b"\x01"):
+        for _ in range(200):
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=5)
+                break
+            except OSError:
+                time.sleep(0.02)
+        launch._send(c, hello)
+        c.close()
+    t1 = threading.Thread(target=run, args=(1,))
+    t1.start()
+    t0.join(60)
+    t1.join(60)
+    assert out == {0: [b"payload-0", b"payload-1"], 1: [b"payload-0", b"payload-1"]}
+    assert launch._unpack_parts(launch._pack_parts([b"", b"ab", b"\x00" * 5]), 3) == [b"", b"ab", b"\x00" * 5]
+    with pytest.raises(ConnectionError):
+        launch._unpack_parts(launch._pack_parts([b"a"]), 2)
+    assert "import pickle" not in open(launch.__file__).read() and not hasattr(launch, "pickle")
+
+
+def test_spawn_tears_the_other_ranks_down_when_one_fails():
+    """a rank that dies while its peers wait for it (here: in a rendezvous receive) must not hang the launcher:
+    spawn() polls every child, terminates the others on the first non-zero exit and returns that code."""
+    from llckbdm_amd.launch import spawn
+    prog = ("import os, sys, time\n"
+            "from llckbdm_amd.launch import Rendezvous\n"
+            "r = int(os.environ['RANK'])\n"
+            "rz = Rendezvous(timeout=120)\n"
+            "rz.barrier()\n"
+            "if r == 1:\n"
+            "    sys.exit(7)\n"
+            "rz.barrier()\n"              # ranks 0 and 2 now wait for rank 1, which is gone
+            "time.sleep(120)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    t0 = time.time()
+    rc = spawn([sys.executable, "-c", prog], 3, env=env)
+    assert rc != 0             # rank 1's 7, or the ConnectionError of a peer that noticed first
+    assert time.time() - t0 < 60
+    assert spawn([sys.executable, "-c", "import os; assert os.environ['KBDM_RDZV_TOKEN']"], 2, env=env) == 0
+
+
 def test_packed_block_layout_roundtrip():
     """Host packing == the layout include/kbdm_hip.h documents for kbdm_plan_gather; sizes match kbdm_packed_bytes."""
     from llckbdm_amd import _lib
@@ -176,6 +279,8 @@ def test_packed_block_layout_roundtrip():
         a, b, c, d = unpack_block(blk, nl, nsv, nb)
         assert np.array_equal(a, lines) and np.array_equal(b, sv) and np.array_equal(c, status)
         assert np.array_equal(d, keep.astype(bool))
+    from llckbdm_amd.distributed import block_trailer, TRAILER_MAGIC
+    assert block_trailer(pack_block(lines, sv, status, keep, rank=5, seq=2 ** 40 + 3)) == (TRAILER_MAGIC, 5, 2 ** 40 + 3)
 
 
 @pytest.mark.gpu

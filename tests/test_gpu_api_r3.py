@@ -23,6 +23,13 @@ def eng():
     e.close()
 
 
+@pytest.fixture(autouse=True)
+def _disarm_status_hook(eng):
+    """The status test hook is process-wide: whatever a test armed is gone before the next one runs."""
+    yield
+    eng.lib.kbdm_debug_force_status(0, 0)
+
+
 def _small_c2(seed, step=6):
     from llckbdm_amd import datasets
     sigs, sig_idx, ms = datasets.config2(seed=seed)
@@ -30,7 +37,7 @@ def _small_c2(seed, step=6):
 
 
 def test_flagged_members_are_retried_and_come_back_correct(eng, monkeypatch):
-    """A status word that reports non-convergence on the first pass only (KBDM_DEBUG_FORCE_STATUS_ONCE: the test hook
+    """A status word that reports non-convergence on the first pass only (kbdm_debug_force_status(0, bits): the test hook
     of kbdm_plan_collect flags every member of the next collected run, then disarms itself): through the drop-in
     `sample_kbdm` the caller never sees it - the flagged members are solved again in the conservative mode (the QR
     iteration in one workgroup per member instead of the Ehrlich-Aberth path) and every kept line agrees with the
@@ -38,11 +45,11 @@ def test_flagged_members_are_retried_and_come_back_correct(eng, monkeypatch):
     from llckbdm_amd.sampling import sample_kbdm
     sigs, _, ms = _small_c2(3)
     good_l, good_i = sample_kbdm(sigs[0], DWELL, ms.tolist(), p=1, l=None, q=0, engine=eng)
-    monkeypatch.setenv("KBDM_DEBUG_FORCE_STATUS_ONCE", "2")
+    eng.lib.kbdm_debug_force_status(0, 2)
     raw = eng.solve(sigs, np.zeros(len(ms), np.int32), ms, ms, p=1, q=0.0, dwell=DWELL)
     assert (raw.status & 2).all()
     assert not eng.solve(sigs, np.zeros(len(ms), np.int32), ms, ms, p=1, q=0.0, dwell=DWELL).status.any()   # disarmed
-    monkeypatch.setenv("KBDM_DEBUG_FORCE_STATUS_ONCE", "2")
+    eng.lib.kbdm_debug_force_status(0, 2)
     got_l, got_i = sample_kbdm(sigs[0], DWELL, ms.tolist(), p=1, l=None, q=0, engine=eng)
     assert len(got_l) == len(good_l)
     from tests.helpers import assert_lines_close, canonical
@@ -61,22 +68,22 @@ def test_failure_that_survives_the_retry_raises_linalgerror(eng, monkeypatch):
     from llckbdm_amd.kbdm import kbdm
     from llckbdm_amd.sampling import sample_kbdm, sample_kbdm_signals
     sigs, _, ms = _small_c2(4, step=30)
-    monkeypatch.setenv("KBDM_DEBUG_FORCE_STATUS", "2")         # every member reports EIG_NOCONV, the retry too
+    eng.lib.kbdm_debug_force_status(2, 0)         # every member reports EIG_NOCONV, the retry too
     with pytest.raises(np.linalg.LinAlgError, match="eig algorithm did not converge"):
         sample_kbdm(sigs[0], DWELL, ms.tolist(), p=1, l=None, q=0, engine=eng)
     with pytest.raises(np.linalg.LinAlgError):
         kbdm(sigs[0], DWELL, m=64, engine=eng)
     with pytest.raises(np.linalg.LinAlgError):
         sample_kbdm_signals(sigs, DWELL, [0, 0], [64, 80], engine=eng)
-    monkeypatch.setenv("KBDM_DEBUG_FORCE_STATUS", "1")
+    eng.lib.kbdm_debug_force_status(1, 0)
     with pytest.raises(np.linalg.LinAlgError, match="SVD did not converge"):
         kbdm(sigs[0], DWELL, m=64, engine=eng)
-    monkeypatch.setenv("KBDM_DEBUG_FORCE_STATUS", "4")         # INVIT_WEAK: a warning, results returned
+    eng.lib.kbdm_debug_force_status(4, 0)         # INVIT_WEAK: a warning, results returned
     from llckbdm_amd.engine import KbdmAccuracyWarning
     with pytest.warns(KbdmAccuracyWarning):
         ll, info = kbdm(sigs[0], DWELL, m=64, engine=eng)
     assert ll.shape == (64, 4)
-    monkeypatch.delenv("KBDM_DEBUG_FORCE_STATUS")
+    eng.lib.kbdm_debug_force_status(0, 0)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         kbdm(sigs[0], DWELL, m=64, engine=eng)                 # and silence without the hook

@@ -23,7 +23,7 @@ def hs():
     inc = os.path.join(ROOT, "llckbdm_amd", "csrc")
     deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc)]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, src, "-o", so], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-I", inc, src, "-o", so], check=True)
     return ctypes.CDLL(so)
 
 
@@ -324,3 +324,52 @@ def test_divide_and_conquer_aberth_eigenvalues(hs):
     A = np.triu(A, -1)
     A[40, 39] = 0.0                                            # an exact split
     assert run(A)[1] == 1
+
+
+def test_cooperative_panels_give_the_same_bits_for_every_team_size(hs, monkeypatch):
+    """kb_team.hpp / kb_panel_team.hpp: the panels of the two blocked reductions run by teams of T "workgroups" (here T
+    threads that meet in a barrier, sharing the matrices and the exchange buffer as the device's workgroups do) return the
+    same BITS for every T - the split products are defined by a fixed slot decomposition, T only deals the slots - and
+    they agree with the round-3 one-workgroup panels to rounding."""
+    rng = np.random.default_rng(5)
+
+    def bidiag(A):
+        m = A.shape[0]
+        Af = np.asfortranarray(A)
+        d, e = np.zeros(m), np.zeros(m)
+        Q, Pm = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F")
+        hs.hs_bidiag(Af.ctypes.data_as(P), m, d.ctypes.data_as(P), e.ctypes.data_as(P), Q.ctypes.data_as(P), Pm.ctypes.data_as(P))
+        return d, e, Q, Pm
+
+    def eig(W):
+        n = W.shape[0]
+        Wf = np.asfortranarray(W)
+        mu, Pm = np.zeros(n, complex), np.zeros((n, n), complex, order="F")
+        info = hs.hs_eig(Wf.ctypes.data_as(P), n, mu.ctypes.data_as(P), Pm.ctypes.data_as(P))
+        return mu, Pm, info
+
+    for m in (97, 161):                     # one and three panels of 32 columns
+        A = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        W = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        monkeypatch.setenv("HS_BIDIAG_FUSED", "0")
+        d0 = bidiag(A)[0]
+        monkeypatch.delenv("HS_BIDIAG_FUSED")
+        monkeypatch.setenv("HS_HESS_OLD", "1")
+        mu0 = eig(W)[0]
+        monkeypatch.delenv("HS_HESS_OLD")
+        base = None
+        for T in (1, 2, 3, 8):
+            monkeypatch.setenv("HS_PANEL_T", str(T))
+            d, e, Q, Pm = bidiag(A)
+            mu, X, info = eig(W)
+            assert info == 0
+            if base is None:
+                base = (d, e, Q, Pm, mu, X)
+                B = np.diag(d) + np.diag(e[:m - 1], 1)
+                assert np.abs(Q @ B @ Pm.conj().T - A).max() < 1e-13 * m
+                assert np.abs(d - d0).max() < 1e-11 and np.abs(np.sort_complex(mu) - np.sort_complex(mu0)).max() < 1e-10
+                assert np.abs(W @ X - X * mu).max() < 1e-12 * m
+            else:
+                for a, b in zip(base, (d, e, Q, Pm, mu, X)):
+                    assert np.array_equal(a, b), f"team of {T} differs from a team of one (m = {m})"
+        monkeypatch.delenv("HS_PANEL_T")

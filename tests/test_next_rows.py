@@ -106,6 +106,25 @@ def test_llc_kbdm_host_logic(gnext):
     assert len(results.silhouette) == len(results.line_list) and results.rmse < 1e-6
 
 
+def test_llc_kbdm_has_no_silent_host_clusterer(gnext, monkeypatch):
+    """a sweep whose min_samples exceed what the GPU clusterer holds raises (naming the explicit opt-in)
+    instead of handing those fits to scikit-learn on the host behind the caller's back."""
+    import llckbdm_amd.llckbdm as M
+
+    class Eng(OracleEngine):
+        def hdbscan_sweep(self, X, ks, mcs=5):
+            assert max(ks) <= M.GPU_SWEEP_MAX_K
+            return super().hdbscan_sweep(X, ks, mcs)
+    sig = gnext["sig2048"]
+    monkeypatch.setattr(M, "GPU_SWEEP_MAX_K", 3)
+    with pytest.raises(ValueError, match="clusterer='sklearn'"):
+        M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(250, 256), p=1, l=30, engine=Eng())
+    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(250, 254), p=1, l=30, engine=Eng())      # sweep 1..3: on the "GPU"
+    assert len(res.line_list) > 0
+    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(250, 256), p=1, l=30, engine=Eng(), clusterer="sklearn")
+    assert len(res.line_list) > 0
+
+
 def test_hdbscan_tree_part_against_sklearn():
     """The host half of the built-in HDBSCAN* (C ABI kbdm_hdbscan_labels_from_mst, no GPU needed): fed with a
     numpy Prim MST of the mutual-reachability graph it reproduces scikit-learn's partitions (same number of
