@@ -305,9 +305,14 @@ def main():
     ap.add_argument("--sharded", action="store_true",
                     help="strong scaling: ONE job dealt over the ranks (shard_items) + the RCCL gather per step")
     ap.add_argument("--no-extras", action="store_true", help="skip host_to_host / other_configs")
+    ap.add_argument("--trace-mode", action="store_true",
+                    help="for rocprofv3 runs: every ensemble of the process runs with --in-flight ensembles in flight (warm-up "
+                         "included), nothing else runs (no one-at-a-time pass, no clean pass, no sampler call, no extras, no CPU baseline)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="submit the ensembles of a burst at once instead of a fraction of a cycle apart")
     args = ap.parse_args()
+    if args.trace_mode:
+        args.no_extras = args.no_cpu_baseline = True
     if args.workload is None:
         args.workload = "C5" if args.sharded else "C2"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -400,10 +405,11 @@ def main():
 
     # warm-up: one ensemble at a time, which also gives the single-ensemble latency; every context runs once
     latency = None
-    for s in range(max(args.warmup, nfl)):
-        tw = run_api_loop(eng, [works[s % nfl]], 1, 1, resident=True, on_done=on_done)
-        latency = tw if latency is None else min(latency, tw)
-    run_api_loop(eng, works, nfl, nfl, resident=True, on_done=on_done)      # every context holds its plan + signals
+    if not args.trace_mode:
+        for s in range(max(args.warmup, nfl)):
+            tw = run_api_loop(eng, [works[s % nfl]], 1, 1, resident=True, on_done=on_done)
+            latency = tw if latency is None else min(latency, tw)
+    run_api_loop(eng, works, max(nfl, args.warmup if args.trace_mode else 0), nfl, resident=True, on_done=on_done)      # every context holds its plan + signals
     sync_ranks()
     timed[0] = True
     t0 = time.perf_counter()
@@ -415,11 +421,15 @@ def main():
     timed[0] = False
 
     # ---- verification outside the timed region: every member converged; (multi) the gathered blocks are the results
-    last = eng.submit(*works[0][:3], works[0][2], p=1, q=0.0, dwell=DWELL, resident=True)
-    ref = last.result(check=False)
-    ok = int((ref.status == 0).sum())
-    n0 = last.plan.lane0_members()        # members (the largest) whose stage timers `stage_ms` reports
-    nfb = last.plan.eig_fallbacks()       # members the Ehrlich-Aberth eigenvalue path handed to the QR iteration
+    if args.trace_mode and not multi:     # (no lone ensemble in a trace that is meant to be all in flight)
+        pl0 = next(iter(eng._slots[0].plans.values()))
+        ok, n0, nfb, last, ref = len(ms), pl0.lane0_members(), pl0.eig_fallbacks(), None, None
+    else:
+        last = eng.submit(*works[0][:3], works[0][2], p=1, q=0.0, dwell=DWELL, resident=True)
+        ref = last.result(check=False)
+        ok = int((ref.status == 0).sum())
+        n0 = last.plan.lane0_members()        # members (the largest) whose stage timers `stage_ms` reports
+        nfb = last.plan.eig_fallbacks()       # members the Ehrlich-Aberth eigenvalue path handed to the QR iteration
     if multi:
         buf = comms[last._slot.ctx.value].gather_plan(last.plan, sizes, root=-1)       # to every rank, for the check
         off = int(sizes[:rank].sum())
@@ -435,7 +445,7 @@ def main():
     # ---- the same steps one at a time, host -> host, and the other configurations (N = 1 only)
     serial = host_incl = clean = sample_call = llc_call = None
     others = {}
-    if not multi:
+    if not multi and not args.trace_mode:
         ns_ser = min(args.steps, 5)
         if nfl > 1:
             ser_acc, ser_n = {}, [0]

@@ -33,6 +33,18 @@ constexpr int KB_AB_TILE = 64;        // roots per workgroup
 constexpr int KB_AB_BLK = 32;         // rows per block of the recurrence
 constexpr int KB_AB_INNER_BUDGET = 4;  // iterations of a level below the root of the tree (even: the root buffers alternate)
 static_assert(KB_AB_INNER_BUDGET % 2 == 0, "the root buffers alternate per launch: a level must end on the buffer it started on");
+// The tail of the root level: once a member has at most KB_AB_TAIL_ROOTS unsettled roots (and the tile iterations have had
+// KB_AB_TAIL_FROM launches), every remaining root gets a wavefront of its own (k_ab_tail: Hyman's recurrence column by
+// column, the running sums in registers) instead of a 64-root MFMA tile that costs the same whether it carries one root
+// or 64.  Members of more than KB_AB_TAIL_MAXL rows stay on the tile kernel (the register-resident sums).
+constexpr int KB_AB_TAIL_FROM = 4;
+constexpr int KB_AB_TAIL_ROOTS = 48;
+constexpr int KB_AB_TAIL_WGS = 12;     // workgroups of four wavefronts per member: one root per wavefront
+constexpr int KB_AB_TAIL_MAXC = 8;
+constexpr int KB_AB_TAIL_MAXL = 64 * KB_AB_TAIL_MAXC;
+KB_HD bool ab_tail_takes(int l, int depth, int iter, int nactive) {
+    return depth == 0 && iter >= KB_AB_TAIL_FROM && l <= KB_AB_TAIL_MAXL && nactive <= KB_AB_TAIL_ROOTS;
+}
 
 struct AbNode { int a, n; };
 
@@ -114,6 +126,14 @@ KB_HD bool ab_converged(double dz, cd z, double hnorm) { return dz <= 1e-10 * fm
 // the iterations of the root level unchanged, 3e-2 costs it half as many again)
 KB_HD bool ab_converged_inner(double dz, cd z, double hnorm) { return dz <= 1e-3 * fmax(cabs(z), 1e-6 * hnorm); }
 KB_HD bool ab_acceptable(double dz, cd z, double hnorm) { return dz <= 1e-9 * fmax(cabs(z), 1e-6 * hnorm); }
+
+// The last correction dz certifies a root to working precision when dz^3 / sep^2 (the error a cubically convergent step
+// leaves behind, sep = distance to the nearest other root) is below 1e-17 of the root's scale.  sep2 = sep^2.
+KB_HD bool ab_certified(double dz, cd z, double hnorm, double sep2) {
+    const double sc = fmax(cabs(z), 1e-6 * hnorm);
+    const double r = dz / sc;
+    return r * r * r <= 1e-17 * (sep2 / (sc * sc));
+}
 
 // A subdiagonal entry that small splits the matrix: Hyman's recurrence divides by it (the QR iteration deflates there)
 KB_HD bool ab_negligible_sub(cd hsub, cd hk, cd hk1) {
@@ -197,6 +217,12 @@ inline int ab_host_eig(const cd* H, int ld, int n, double hnorm, cd* w, LeafSolv
             for (int j = 0; j < nd.n; ++j)
                 if (!ab_acceptable(lastc[nd.a + j], zz[j], hnorm)) return 1;
         }
+    for (int k = 0; k < n && n > 1; ++k) {                  // (the root level's roots: certified by their separation)
+        double sep2 = 1.79769313486231570815e308;
+        for (int j = 0; j < n; ++j)
+            if (j != k) { const cd dd = z[k] - z[j]; sep2 = fmin(sep2, dd.x * dd.x + dd.y * dd.y); }
+        if (!ab_certified(lastc[k], z[k], hnorm, sep2)) return 1;
+    }
     if (iters_out) *iters_out = iters;
     // power sums against the traces
     cd t1 = czero(), t2 = czero(), s1 = czero(), s2 = czero();

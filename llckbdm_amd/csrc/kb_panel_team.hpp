@@ -25,6 +25,7 @@ __device__ unsigned long long kb_panel_prof[32];
 #define KB_PROF_SYNC(ph_) do { } while (0)
 #endif
 
+
 namespace kb {
 
 // LDS: column (n) + row (n) + raw dots / y_j (n) + x_{j-1} (n) + sweep results (2 n) + row-product partial sums (NCG x zr)
@@ -51,13 +52,32 @@ KB_HD void team_row_product(const C& ctx, const PanelTeam<C>& tm, int nr, int nc
         if (i < nr) {
             cd acc = czero(), acc1 = czero(), acc2 = czero(), acc3 = czero();
             int c = cg;
-            for (; c + 3 * KB_TEAM_NCG < ncols; c += 4 * KB_TEAM_NCG) {       // four independent loads in flight
+            for (; c + 7 * KB_TEAM_NCG < ncols; c += 8 * KB_TEAM_NCG) {       // eight independent loads in flight
+                const cd* __restrict__ ap = Ab + i + (size_t)c * ld;
+                const size_t st = (size_t)KB_TEAM_NCG * ld;
+                const cd a0 = ap[0], a1 = ap[st], a2 = ap[2 * st], a3 = ap[3 * st];
+                const cd a4 = ap[4 * st], a5 = ap[5 * st], a6 = ap[6 * st], a7 = ap[7 * st];
+                cfma(acc, a0, u[c]); cfma(acc1, a1, u[c + KB_TEAM_NCG]);
+                cfma(acc2, a2, u[c + 2 * KB_TEAM_NCG]); cfma(acc3, a3, u[c + 3 * KB_TEAM_NCG]);
+                cfma(acc, a4, u[c + 4 * KB_TEAM_NCG]); cfma(acc1, a5, u[c + 5 * KB_TEAM_NCG]);
+                cfma(acc2, a6, u[c + 6 * KB_TEAM_NCG]); cfma(acc3, a7, u[c + 7 * KB_TEAM_NCG]);
+            }
+            for (; c + 3 * KB_TEAM_NCG < ncols; c += 4 * KB_TEAM_NCG) {       // four
                 const cd a0 = Ab[i + (size_t)c * ld], a1 = Ab[i + (size_t)(c + KB_TEAM_NCG) * ld];
                 const cd a2 = Ab[i + (size_t)(c + 2 * KB_TEAM_NCG) * ld], a3 = Ab[i + (size_t)(c + 3 * KB_TEAM_NCG) * ld];
                 cfma(acc, a0, u[c]); cfma(acc1, a1, u[c + KB_TEAM_NCG]);
                 cfma(acc2, a2, u[c + 2 * KB_TEAM_NCG]); cfma(acc3, a3, u[c + 3 * KB_TEAM_NCG]);
             }
-            for (; c < ncols; c += KB_TEAM_NCG) cfma(acc, Ab[i + (size_t)c * ld], u[c]);
+            if (c < ncols) {                                                   // up to three columns left: their loads together
+                const int c1 = c + KB_TEAM_NCG, c2 = c + 2 * KB_TEAM_NCG;
+                const bool h1 = c1 < ncols, h2 = c2 < ncols;
+                const cd a0 = Ab[i + (size_t)c * ld];
+                const cd a1 = h1 ? Ab[i + (size_t)c1 * ld] : czero();
+                const cd a2 = h2 ? Ab[i + (size_t)c2 * ld] : czero();
+                cfma(acc, a0, u[c]);
+                if (h1) cfma(acc1, a1, u[c1]);
+                if (h2) cfma(acc2, a2, u[c2]);
+            }
             zp[cg * zr + kk * C::WS + lane] = (acc + acc1) + (acc2 + acc3);
         }
     }
@@ -117,6 +137,40 @@ KB_HD void team_sweep8(const C& ctx, int nq, FP part, FO out) {
             if (act && g == 0) out(q, a, b);
         }
     }
+}
+
+// Column dots  yr[c] = A0[j:, c]^H v  for the blocks of KB_TEAM_CB columns this workgroup owns (block b = role + kb T:
+// columns j + 1 + b CB ...): one wavefront per pair of columns, lanes along the rows, eight loads in flight.
+template <class C>
+KB_HD void team_col_dots(const C& ctx, int role, int T, int nownb, int n, int j, const cd* __restrict__ A, int ld,
+                                     const cd* vc, cd* yr) {
+#define A_(r_, c_) A[(r_) + (size_t)(c_) * ld]
+    const int lane = ctx.lane(), nw = ctx.nwaves();
+    for (int pp = ctx.wave(); pp < nownb * (KB_TEAM_CB / 2); pp += nw) {
+        const int kb = pp / (KB_TEAM_CB / 2), pr = pp - kb * (KB_TEAM_CB / 2);
+        const int c0 = j + 1 + (role + kb * T) * KB_TEAM_CB + 2 * pr;
+        if (c0 >= n) continue;
+        const int c1 = (c0 + 1 < n) ? c0 + 1 : c0;
+        cd g0 = czero(), g1 = czero(), h0 = czero(), h1 = czero();
+        int r = j + lane;
+        for (; r + C::WS < n; r += 2 * C::WS) {
+            const cd a00 = A_(r, c0), a01 = A_(r, c1), a10 = A_(r + C::WS, c0), a11 = A_(r + C::WS, c1);
+            const cd v0 = vc[r], v1 = vc[r + C::WS];
+            cfmac(g0, a00, v0); cfmac(g1, a01, v0); cfmac(h0, a10, v1); cfmac(h1, a11, v1);
+        }
+        for (; r < n; r += C::WS) {
+            const cd a00 = A_(r, c0), a01 = A_(r, c1);
+            const cd v0 = vc[r];
+            cfmac(g0, a00, v0); cfmac(g1, a01, v0);
+        }
+        const cd s0 = ctx.wave_sum(g0 + h0);
+        const cd s1 = ctx.wave_sum(g1 + h1);
+        if (lane == 0) {
+            yr[c0] = s0;
+            if (c0 + 1 < n) yr[c0 + 1] = s1;
+        }
+    }
+#undef A_
 }
 
 // ---------------------------------------------------------------------------------
@@ -188,30 +242,7 @@ KB_HD bool bidiag_panel_team(const C& ctx, PanelTeam<C>& tm, int n, cd* A, int l
         const int nr = n - j - 1;
         const int nblk = (nr + KB_TEAM_CB - 1) / KB_TEAM_CB;
         const int nownb = team_own_count(nblk, role, T);
-        for (int pp = ctx.wave(); pp < nownb * (KB_TEAM_CB / 2); pp += nw) {
-            const int kb = pp / (KB_TEAM_CB / 2), pr = pp - kb * (KB_TEAM_CB / 2);
-            const int c0 = j + 1 + (role + kb * T) * KB_TEAM_CB + 2 * pr;
-            if (c0 >= n) continue;
-            const int c1 = (c0 + 1 < n) ? c0 + 1 : c0;
-            cd g0 = czero(), g1 = czero(), h0 = czero(), h1 = czero();
-            int r = j + lane;
-            for (; r + C::WS < n; r += 2 * C::WS) {
-                const cd a00 = A_(r, c0), a01 = A_(r, c1), a10 = A_(r + C::WS, c0), a11 = A_(r + C::WS, c1);
-                const cd v0 = vc[r], v1 = vc[r + C::WS];
-                cfmac(g0, a00, v0); cfmac(g1, a01, v0); cfmac(h0, a10, v1); cfmac(h1, a11, v1);
-            }
-            for (; r < n; r += C::WS) {
-                const cd a00 = A_(r, c0), a01 = A_(r, c1);
-                const cd v0 = vc[r];
-                cfmac(g0, a00, v0); cfmac(g1, a01, v0);
-            }
-            const cd s0 = ctx.wave_sum(g0 + h0);
-            const cd s1 = ctx.wave_sum(g1 + h1);
-            if (lane == 0) {
-                yr[c0] = s0;
-                if (c0 + 1 < n) yr[c0 + 1] = s1;
-            }
-        }
+        team_col_dots(ctx, role, T, nownb, n, j, A, ld, vc, yr);
         ctx.sync_lds();
         KB_PROF(3);
         // ---- row j of H_j^H A^(j), columns j+1.., conjugated, and y_c: the owned columns
@@ -219,7 +250,16 @@ KB_HD bool bidiag_panel_team(const C& ctx, PanelTeam<C>& tm, int n, cd* A, int l
             [&](int q, int g, cd& acc, cd& co) {
                 const int c = j + 1 + (role + (q / KB_TEAM_CB) * T) * KB_TEAM_CB + (q % KB_TEAM_CB);
                 if (c >= n) return;
-                for (int t = g; t < j; t += KB_SWEEP_G) {
+                int t = g;
+                for (; t + KB_SWEEP_G < j; t += 2 * KB_SWEEP_G) {              // two reflectors per step: four loads in flight
+                    const int t2 = t + KB_SWEEP_G;
+                    const cd yct = Y_(c, t), uct = U_(c, t), yc2 = Y_(c, t2), uc2 = U_(c, t2);
+                    acc = acc + ra[t] * conj(yct) + rb[t] * conj(uct);
+                    co = co + yct * w1[t] + uct * w2[t];
+                    acc = acc + ra[t2] * conj(yc2) + rb[t2] * conj(uc2);
+                    co = co + yc2 * w1[t2] + uc2 * w2[t2];
+                }
+                if (t < j) {
                     const cd yct = Y_(c, t), uct = U_(c, t);
                     acc = acc + ra[t] * conj(yct) + rb[t] * conj(uct);
                     co = co + yct * w1[t] + uct * w2[t];
@@ -295,7 +335,20 @@ KB_HD bool bidiag_panel_team(const C& ctx, PanelTeam<C>& tm, int n, cd* A, int l
                 const int i = (role + (q / C::WS) * T) * C::WS + (q % C::WS);
                 if (i >= nr) return;
                 const int r = j + 1 + i;
-                for (int t = g; t <= j; t += KB_SWEEP_G) {
+                int t = g;
+                for (; t + KB_SWEEP_G < j; t += 2 * KB_SWEEP_G) {              // (both reflectors below j: X exists for them)
+                    const int t2 = t + KB_SWEEP_G;
+                    const cd art = A_(r, t), xrt = X_(r, t), ar2 = A_(r, t2), xr2 = X_(r, t2);
+                    hp = hp + art * z1[t];
+                    if (nextcol) np = np + art * conj(ra[t]);
+                    hp = hp + xrt * z2[t];
+                    if (nextcol) np = np + xrt * conj(rb[t]);
+                    hp = hp + ar2 * z1[t2];
+                    if (nextcol) np = np + ar2 * conj(ra[t2]);
+                    hp = hp + xr2 * z2[t2];
+                    if (nextcol) np = np + xr2 * conj(rb[t2]);
+                }
+                for (; t <= j; t += KB_SWEEP_G) {
                     const cd art = A_(r, t);
                     hp = hp + art * z1[t];
                     if (nextcol) np = np + art * conj(ra[t]);
@@ -406,7 +459,13 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
                 [&](int q, int g, cd& acc, cd& unused) {
                     (void)unused;
                     const int r = p0 + 1 + q;
-                    for (int t = g; t < j; t += KB_SWEEP_G) acc = acc + hess_vt(W, ld, p0, r, t) * w2[t];
+                    int t = g;
+                    for (; t + KB_SWEEP_G < j; t += 2 * KB_SWEEP_G) {
+                        const cd v0 = hess_vt(W, ld, p0, r, t), v1 = hess_vt(W, ld, p0, r, t + KB_SWEEP_G);
+                        acc = acc + v0 * w2[t];
+                        acc = acc + v1 * w2[t + KB_SWEEP_G];
+                    }
+                    if (t < j) acc = acc + hess_vt(W, ld, p0, r, t) * w2[t];
                 },
                 [&](int q, cd acc, cd unused) {
                     (void)unused;
@@ -445,7 +504,16 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
             [&](int q, int g, cd& hp, cd& np) {
                 const int r = (role + (q / C::WS) * T) * C::WS + (q % C::WS);
                 if (r >= N) return;
-                for (int t = g; t < j; t += KB_SWEEP_G) {
+                int t = g;
+                for (; t + KB_SWEEP_G < j; t += 2 * KB_SWEEP_G) {
+                    const int t2 = t + KB_SWEEP_G;
+                    const cd yrt = Y_(r, t), yr2 = (t2 == j - 1) ? yl[r] : Y_(r, t2);
+                    hp = hp + yrt * w1[t];
+                    if (nextcol) np = np + yrt * conj(ra[t]);
+                    hp = hp + yr2 * w1[t2];
+                    if (nextcol) np = np + yr2 * conj(ra[t2]);
+                }
+                if (t < j) {
                     const cd yrt = (t == j - 1) ? yl[r] : Y_(r, t);
                     hp = hp + yrt * w1[t];
                     if (nextcol) np = np + yrt * conj(ra[t]);

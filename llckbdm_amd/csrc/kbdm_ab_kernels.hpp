@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     const KbItem it = items[item];
     const int l = it.l, depth = ab_depth(l) - 1 - step;
     if (depth < 0) return;
+    const bool tail_on = (dbg & 16) == 0;                   // (the host sets bit 16 when k_ab_tail is not launched)
     const int Tl = (ab_level_nmax(l, depth) + KB_AB_TILE - 1) / KB_AB_TILE;
     const int idx = blockIdx.x / Tl, tile = blockIdx.x % Tl;
     if (idx >= (1 << depth)) return;
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         }
     __syncthreads();
     const int nactive = L.flags[0];
+    if (tail_on && ab_tail_takes(l, depth, iter, nactive)) return;     // the few roots left get a wavefront each (k_ab_tail)
     const int nr = (nactive - tile * KB_AB_TILE < KB_AB_TILE) ? nactive - tile * KB_AB_TILE : KB_AB_TILE;
     if (nr <= 0) return;                                    // this tile has nothing left to iterate
     if (abstat && t == 0) atomicAdd(&abstat[step * KB_AB_BUDGET + iter], 1);
@@ -578,6 +580,192 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
     }
 }
 
+// The tail of a member's root level (kb_aberth.hpp: ab_tail_takes): ONE Aberth iteration of each of its few unsettled
+// roots, one wavefront per root, four roots per workgroup.  Hyman's recurrence runs column by column: when x_j is known,
+// column j of H (rows 0 .. j) is added to the running row sums, which live in registers (row r on lane r mod 64, chunk
+// r / 64: static indices, the loop over the chunk of the pivot row is unrolled); the finished sum of row j comes back
+// through v_readlane and gives x_{j-1}.  The derivative runs alongside.  All four wavefronts walk the same columns in the
+// same order, so the workgroup streams H through LDS in blocks of KB_AB_TAIL_CB columns (double buffered: the global loads
+// of the next block travel under the arithmetic of this one; a step costs no memory latency).  Columns are rescaled by
+// powers of two every 32 steps.  grid (KB_AB_TAIL_WGS, members), 256 threads; dynamic LDS: ab_tail_lds_bytes(lmax).
+constexpr int KB_AB_TAIL_CB = 8;
+constexpr int KB_AB_TAIL_NREG = KB_AB_TAIL_CB * KB_AB_TAIL_MAXL / 256;      // elements of a block per thread
+// element i of a thread's share of a block: column i mod CB, row t + 256 (i / CB) - no divisions, coalesced along the rows
+#define KB_TAIL_LOAD(B_)                                                                                   \
+    {                                                                                                      \
+        const int rows_ = (CB * (B_) + CB < n) ? CB * (B_) + CB : n;                                       \
+        _Pragma("unroll") for (int i = 0; i < KB_AB_TAIL_NREG; ++i) {                                      \
+            const int jj_ = i % CB, r_ = t + 256 * (i / CB), j_ = CB * (B_) + jj_;                         \
+            regs[i] = (r_ < rows_ && j_ < n) ? H[r_ + (size_t)j_ * l] : kb::czero();                       \
+        }                                                                                                  \
+    }
+#define KB_TAIL_STORE(B_, buf_)                                                                            \
+    {                                                                                                      \
+        const int rows_ = (CB * (B_) + CB < n) ? CB * (B_) + CB : n;                                       \
+        _Pragma("unroll") for (int i = 0; i < KB_AB_TAIL_NREG; ++i) {                                      \
+            const int jj_ = i % CB, r_ = t + 256 * (i / CB);                                               \
+            if (r_ < rows_) (buf_)[jj_ * npad + r_] = regs[i];                                             \
+        }                                                                                                  \
+    }
+// The steps of the recurrence whose pivot row lies in chunk CJ (rows 64 CJ .. 64 CJ + 63): a template, so that every index
+// into the register arrays is a compile-time constant.
+template <int CJ>
+__device__ __forceinline__ void ab_tail_chunk(kb::cd& sx_, kb::cd& sy_, kb::cd& srho_, kb::cd& srhop_, int& scur_, kb::cd (&Sx)[KB_AB_TAIL_MAXC], kb::cd (&Sy)[KB_AB_TAIL_MAXC],
+                                              kb::cd (&regs)[KB_AB_TAIL_NREG], const kb::cd* __restrict__ H, int l, int n, int npad,
+                                              int Bmax, int t, int lane, bool act, kb::cd z, const kb::cd* inv, kb::cd* colbuf) {
+    using namespace kb;
+    constexpr int MAXC = KB_AB_TAIL_MAXC, CB = KB_AB_TAIL_CB;
+    if (CJ * 64 >= n) return;
+    const int Bhi = (CJ * (64 / CB) + (64 / CB) - 1 < Bmax) ? CJ * (64 / CB) + (64 / CB) - 1 : Bmax;
+    for (int B = Bhi; B >= CJ * (64 / CB); --B) {
+        if (B > 0) KB_TAIL_LOAD(B - 1)                       // in flight under this block's arithmetic
+        const cd* buf = colbuf + (size_t)scur_ * CB * npad;
+        if (act) {
+#pragma unroll
+            for (int jj = CB - 1; jj >= 0; --jj) {
+                const int j = CB * B + jj;
+                if (j >= n) continue;
+                const int p = j & 63;
+#pragma unroll
+                for (int c = 0; c <= CJ; ++c) {
+                    const int r = lane + 64 * c;
+                    const cd h = (r <= j) ? buf[jj * npad + r] : czero();
+                    cfma(Sx[c], h, sx_); cfma(Sy[c], h, sy_);
+                }
+                // row j is complete
+                const cd sj = mk(DevCtx::lane_f64(Sx[CJ].x, p), DevCtx::lane_f64(Sx[CJ].y, p));
+                const cd spj = mk(DevCtx::lane_f64(Sy[CJ].x, p), DevCtx::lane_f64(Sy[CJ].y, p));
+                const cd s = sj - z * sx_;
+                const cd sp = (spj - z * sy_) - sx_;
+                if (j > 0) {
+                    const cd iv = inv[j];
+                    sx_ = -(s * iv);
+                    sy_ = -(sp * iv);
+                    if (((n - j) & 31) == 0) {                     // rescale by a power of two (only rho / rho' is used)
+                        const double mx = fmax(fabs(sx_.x), fabs(sx_.y));
+                        int e = 0;
+                        if (mx > 0.0 && mx == mx && mx < 1.79769313486231570815e308) (void)frexp(mx, &e);
+                        if (e > 60 || e < -60) {
+                            const double f = ldexp(1.0, -e);
+                            sx_ = f * sx_; sy_ = f * sy_;
+#pragma unroll
+                            for (int c = 0; c < MAXC; ++c) { Sx[c] = f * Sx[c]; Sy[c] = f * Sy[c]; }
+                        }
+                    }
+                } else {
+                    srho_ = s; srhop_ = sp;
+                }
+            }
+        }
+        if (B > 0) KB_TAIL_STORE(B - 1, colbuf + (size_t)(scur_ ^ 1) * CB * npad)
+        __syncthreads();
+        scur_ ^= 1;
+    }
+}
+KB_HD int ab_tail_npad(int l) { return (l + 63) & ~63; }
+KB_HD int ab_tail_lds_bytes(int l) { return (1 + 2 * KB_AB_TAIL_CB) * ab_tail_npad(l) * (int)sizeof(kb::cd); }
+__global__ void __launch_bounds__(256) k_ab_tail(const kb::KbItem* __restrict__ items, const int* __restrict__ perm,
+                                                  const kb::cd* __restrict__ arena, const double* __restrict__ varena, double* dcarena,
+                                                  const int* __restrict__ needqr, int step, int iter, int* abstat, int npad) {
+    using namespace kb;
+    constexpr int MAXC = KB_AB_TAIL_MAXC, CB = KB_AB_TAIL_CB;
+    const int item = perm[blockIdx.y];
+    if (needqr[item]) return;
+    const KbItem it = items[item];
+    const int l = it.l, depth = ab_depth(l) - 1 - step;
+    if (depth != 0 || l > KB_AB_TAIL_MAXL || iter < KB_AB_TAIL_FROM) return;
+    const int n = l;
+    __shared__ int s_cnt[256];
+    __shared__ int s_ridx[KB_AB_TAIL_ROOTS];
+    __shared__ int s_nact;
+    cd* inv = reinterpret_cast<cd*>(kb_smem);                // 1 / H[k, k-1]
+    cd* colbuf = inv + npad;                                 // two blocks of CB columns x npad rows
+    const AbWs ws = ab_item_ws(it, dcarena);
+    const int bin = (step * KB_AB_BUDGET + iter) & 1;
+    const cd* zin = ws.z[bin];
+    cd* zout = ws.z[bin ^ 1];
+    const int* cin = ws.conv[bin];
+    int* cout = ws.conv[bin ^ 1];
+    const cd* __restrict__ H = arena + it.off[KB_BUF_H];
+    const double hnorm = varena[it.voff + KB_V_MISC * it.vstride];
+    const int t = threadIdx.x;
+    // the unsettled roots of the member (the same scan as k_ab_iter's: both see the flags of the previous iteration)
+    const int per = (n + 255) / 256;
+    const int j0 = t * per, j1 = (j0 + per < n) ? j0 + per : n;
+    {
+        int c = 0;
+        for (int j = j0; j < j1; ++j)
+            if (!cin[j]) ++c;
+        s_cnt[t] = c;
+    }
+    __syncthreads();
+    int rank = 0;
+    for (int u = 0; u < t; ++u) rank += s_cnt[u];
+    if (t == 255) s_nact = rank + s_cnt[255];
+    __syncthreads();
+    const int nactive = s_nact;
+    if (!ab_tail_takes(l, depth, iter, nactive)) return;     // k_ab_iter has this member in this iteration
+    if (blockIdx.x == 0)
+        for (int j = j0; j < j1; ++j)
+            if (cin[j]) { zout[j] = zin[j]; cout[j] = 1; }   // settled roots are carried through
+    if ((int)blockIdx.x * 4 >= nactive) return;              // no root for this workgroup
+    for (int j = j0; j < j1; ++j)
+        if (!cin[j]) s_ridx[rank++] = j;
+    for (int k = 1 + t; k < n; k += 256) inv[k] = ab_recip(H[k + (size_t)(k - 1) * l]);
+    const int wave = t >> 6, lane = t & 63;
+    const int q = blockIdx.x * 4 + wave;
+    const bool act = q < nactive;                            // (wavefront-uniform)
+    // block B = columns CB B .. CB B + CB - 1 (< n), rows 0 .. rows(B) - 1
+    const int Bmax = (n - 1) / CB;
+    cd regs[KB_AB_TAIL_NREG];
+    KB_TAIL_LOAD(Bmax)
+    KB_TAIL_STORE(Bmax, colbuf)
+    __syncthreads();                                         // (also: s_ridx, inv)
+    int me = 0;
+    cd z = czero(), S = czero();
+    if (act) {
+        me = s_ridx[q];
+        z = zin[me];
+        if (abstat && lane == 0) atomicAdd(&abstat[step * KB_AB_BUDGET + iter], 1);
+        // repulsion sum over the other roots (steers the iteration only: reciprocal by the hardware seed + one Newton step)
+        double sx = 0.0, sy = 0.0;
+        for (int j = lane; j < n; j += 64) {
+            if (j == me) continue;
+            const cd d = z - zin[j];
+            const double den = d.x * d.x + d.y * d.y;
+            double iv = __builtin_amdgcn_rcp(den);
+            iv = iv * fma(-den, iv, 2.0);
+            sx = fma(d.x, iv, sx); sy = fma(-d.y, iv, sy);
+        }
+        const DevCtx ctx = make_ctx(0);
+        S = mk(ctx.wave_sum(sx), ctx.wave_sum(sy));
+    }
+    // Hyman's recurrence, columns n-1 .. 0
+    cd Sx[MAXC], Sy[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { Sx[c] = czero(); Sy[c] = czero(); }
+    cd x = mk(1.0, 0.0), y = czero(), rho = czero(), rhop = czero();
+    int cur = 0;
+    ab_tail_chunk<7>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<6>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<5>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<4>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<3>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<2>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<1>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<0>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    if (act && lane == 0) {
+        double dz;
+        const cd zn = ab_update(z, rho, rhop, S, &dz);
+        zout[me] = zn;
+        ws.lastc[me] = dz;
+        cout[me] = ab_converged(dz, zn, hnorm) ? 1 : 0;
+    }
+}
+
+#undef KB_TAIL_LOAD
+#undef KB_TAIL_STORE
+
 __global__ void __launch_bounds__(256) k_ab_finish(const kb::KbItem* __restrict__ items, const int* __restrict__ perm, const kb::cd* arena,
                                                     const double* __restrict__ varena, double* dcarena, kb::cd* mu_out, int* needqr) {
     using namespace kb;
@@ -597,6 +785,17 @@ __global__ void __launch_bounds__(256) k_ab_finish(const kb::KbItem* __restrict_
     for (int k = threadIdx.x; k < l; k += blockDim.x) {
         const cd zk = z[k];
         if (!ab_finite(zk) || !ab_acceptable(ws.lastc[k], zk, hnorm)) bad = 1;
+        // A small last correction certifies a root only where the iteration converges cubically: the error it leaves is
+        // (correction)^3 / (separation)^2.  Inside a cluster tighter than that the convergence is linear and the correction
+        // says little about the error (two approximations can sit next to one eigenvalue): such a member goes to the QR
+        // iteration (kb_aberth.hpp: ab_certified).
+        double sep2 = 1.79769313486231570815e308;
+        for (int j = 0; j < l; ++j) {
+            const cd d = zk - z[j];
+            const double d2 = d.x * d.x + d.y * d.y;
+            if (j != k) sep2 = fmin(sep2, d2);
+        }
+        if (l > 1 && !ab_certified(ws.lastc[k], zk, hnorm, sep2)) bad = 1;
         const cd d = H[k + (size_t)k * l];
         t1 = t1 + d; t2 = t2 + d * d;
         if (k + 1 < l) t2 = t2 + 2.0 * (H[(k + 1) + (size_t)k * l] * H[k + (size_t)(k + 1) * l]);

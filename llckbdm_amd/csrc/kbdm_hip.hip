@@ -127,6 +127,7 @@ struct kbdm_ctx {
                           // they must all be resident: the sum over the contexts of a process must stay below the CU count)
     int panel_T_all = 0;  // KBDM_PANEL_T_ALL=1: teams on every lane (the budget then counts per lane)
     int panel_old = 0;    // KBDM_PANEL_OLD=1: the round-3 one-workgroup panels (A/B)
+    int ab_tail = 1;      // the root level's tail on the wavefront-per-root kernel (KBDM_AB_TAIL=0: tile kernel throughout)
     int ab_dbg = 0;       // KBDM_AB_DBG, read once when the context is created: 8 = phase timers of k_ab_iter (tools/ab_phases.py);
                           // the bits that skip work (2, 4: timing experiments, wrong results) exist in -DKBDM_DEBUG_BUILD libraries only
     double ws_budget_gib = 96.0;
@@ -210,6 +211,7 @@ int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_setup), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_iter), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_tail), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 2048));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_tfac), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_apply), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_APPLY_LDS));
@@ -638,6 +640,12 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
         const bool aberth = ctx->eig_ab && !(pl->mode & KBDM_MODE_SOLO_QR);
         if (aberth) {
             const int Dmax = ab_depth(ch.lmax);
+            int lmin_tail = ch.lmax, ltail = 1;                // smallest member: does any qualify for the tail kernel?  largest that does
+            for (int i = 0; i < ch.count; ++i) {
+                const int l = pl->items[pl->perm[ch.first + i]].l;
+                lmin_tail = std::min(lmin_tail, l);
+                if (l <= KB_AB_TAIL_MAXL) ltail = std::max(ltail, l);
+            }
             int Dmin = Dmax;                                   // steps before Dmin - 1 are inner levels for every member
             std::vector<int> gx(Dmax, 0);                      // workgroups per member and step: tiles x nodes of its level
             {
@@ -663,9 +671,17 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                 for (int s2 = 0; s2 < Dmax; ++s2) nlaunch += (s2 < Dmin - 1 ? KB_AB_INNER_BUDGET : KB_AB_BUDGET);
                 KBracket kb(pl, ch, KBDM_K_AB_ITER, st, nlaunch);
                 for (int s2 = 0; s2 < Dmax; ++s2)
-                    for (int itn = 0; itn < (s2 < Dmin - 1 ? KB_AB_INNER_BUDGET : KB_AB_BUDGET); ++itn)
+                    for (int itn = 0; itn < (s2 < Dmin - 1 ? KB_AB_INNER_BUDGET : KB_AB_BUDGET); ++itn) {
                         hipLaunchKernelGGL(k_ab_iter, dim3(gx[s2], ch.count), dim3(256), sizeof(AbLds), st, pl->d_items, perm, pl->d_arena,
-                                           pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn, pl->d_abstat, ctx->ab_dbg);
+                                           pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn, pl->d_abstat,
+                                           (ctx->ab_dbg & ~16) | (ctx->ab_tail ? 0 : 16));
+                        // the root level's tail: a wavefront per root for members with few unsettled roots left (a member is
+                        // taken by exactly one of the two kernels in an iteration: kb_aberth.hpp, ab_tail_takes)
+                        if (ctx->ab_tail && s2 >= Dmin - 1 && itn >= KB_AB_TAIL_FROM && lmin_tail <= KB_AB_TAIL_MAXL)
+                            hipLaunchKernelGGL(k_ab_tail, dim3(KB_AB_TAIL_WGS, ch.count), dim3(256), ab_tail_lds_bytes(ltail), st, pl->d_items,
+                                               perm, pl->d_arena, pl->d_varena, pl->d_dc, pl->d_needqr, s2, itn, pl->d_abstat,
+                                               ab_tail_npad(ltail));
+                    }
             }
             hipLaunchKernelGGL(k_ab_finish, dim3(ch.count), dim3(256), KB_RED_BYTES, st, pl->d_items, perm, pl->d_arena, pl->d_varena,
                                pl->d_dc, pl->d_mu, pl->d_needqr);
@@ -894,6 +910,7 @@ int kbdm_ctx_create_lanes(int device, int nlanes, kbdm_ctx** out) {
     c->panel_T_all = env_int("KBDM_PANEL_T_ALL", c->panel_T_all);
     c->panel_old = env_int("KBDM_PANEL_OLD", c->panel_old);
     c->ab_dbg = env_int("KBDM_AB_DBG", 0);
+    c->ab_tail = env_int("KBDM_AB_TAIL", c->ab_tail);
 #if !defined(KBDM_DEBUG_BUILD)
     c->ab_dbg &= ~(2 | 4);
 #endif

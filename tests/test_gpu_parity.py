@@ -208,11 +208,25 @@ def test_kbdm_matches_reference_golden(eng, golden, name):
     want = golden[f"{name}__kept"]
     assert len(kept) == len(want), "kept-line count differs from the reference"
     # 1e-8 (north star) everywhere but: the spurious lines of the sigma = 1e-6 case, and m64p2 - 16 peaks in a
-    # noise-free m = 64 Hankel matrix, 48 of the 64 retained singular values are rounding noise and every line carries
-    # eps * 1e8 of it: LAPACK's own two SVD drivers differ by 7.2e-9 on this case and the reference is 7.0e-9 (T2) / 6.7e-9
-    # (phase) from the analytic truth (tools/golden_margin.py prints the margins of every case; this one: 1.05e-8)
+    # noise-free m = 64 Hankel matrix: 48 of the 64 retained singular values ARE rounding noise (100 % relative error), the
+    # reference divides by their square roots, and every genuine line inherits eps * 1e8 of whatever rotation of the noise
+    # space the SVD happened to return.  Measured (tools/m64p2_stage_mix.py, the pipeline with its stages swapped one at a
+    # time): swapping the eigen-solver (zgeev <-> this repository's) moves the lines by 1e-11; swapping the SVD moves them
+    # by 3e-9 (same driver, algebra reordered) ... 7.8e-9 (LAPACK's zgesvd instead of zgesdd) ... 9.2e-9 (this repository's);
+    # the reference itself is 7.0e-9 from the analytic truth.  The reference's output is ONE draw of that noise; another
+    # correct SVD cannot be closer to it than the noise is wide, so this case is compared at 2e-8 AND against the truth below.
     tol = {"n6m256": 1e-6, "m64p2": 2e-8}.get(name, 1e-8)
     assert_lines_close(kept, want, rel=tol, phase_abs=tol, what=name)
+    if name == "m64p2":
+        truth = canonical(np.asarray(golden["params_sorted"], dtype=float))
+        tm = truth[[int(np.argmin(np.abs(truth[:, 2] - w[2]))) for w in want]]
+
+        def from_truth(arr):
+            rel = max(float((np.abs(arr[:, c] - tm[:, c]) / np.abs(tm[:, c])).max()) for c in range(3))
+            return max(rel, float(np.abs(np.angle(np.exp(1j * (arr[:, 3] - tm[:, 3])))).max()))
+        ref_err, our_err = from_truth(want), from_truth(kept)
+        assert 1e-9 < ref_err < 2e-8                       # the reference's own distance from the truth (about 7e-9)
+        assert our_err < 3.0 * ref_err, (our_err, ref_err)  # ours is a draw from the same distribution, not an outlier
     if name in ("c1", "m300", "m150", "m100"):
         truth = golden["params_sorted"]
         g = genuine_rows(kept, truth)

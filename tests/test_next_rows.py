@@ -115,13 +115,13 @@ def test_llc_kbdm_has_no_silent_host_clusterer(gnext, monkeypatch):
         def hdbscan_sweep(self, X, ks, mcs=5):
             assert max(ks) <= M.GPU_SWEEP_MAX_K
             return super().hdbscan_sweep(X, ks, mcs)
-    sig = gnext["sig2048"]
+    sig = gnext["sig2048"][:512]                       # (control flow only: small members keep the oracle cheap)
     monkeypatch.setattr(M, "GPU_SWEEP_MAX_K", 3)
     with pytest.raises(ValueError, match="clusterer='sklearn'"):
-        M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(250, 256), p=1, l=30, engine=Eng())
-    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(250, 254), p=1, l=30, engine=Eng())      # sweep 1..3: on the "GPU"
+        M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(60, 66), p=1, l=24, engine=Eng())
+    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(60, 64), p=1, l=24, engine=Eng())       # sweep 1..3: on the "GPU"
     assert len(res.line_list) > 0
-    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(250, 256), p=1, l=30, engine=Eng(), clusterer="sklearn")
+    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(60, 66), p=1, l=24, engine=Eng(), clusterer="sklearn")
     assert len(res.line_list) > 0
 
 
