@@ -37,7 +37,7 @@ static_assert(KB_AB_INNER_BUDGET % 2 == 0, "the root buffers alternate per launc
 // KB_AB_TAIL_FROM launches), every remaining root gets a wavefront of its own (k_ab_tail: Hyman's recurrence column by
 // column, the running sums in registers) instead of a 64-root MFMA tile that costs the same whether it carries one root
 // or 64.  Members of more than KB_AB_TAIL_MAXL rows stay on the tile kernel (the register-resident sums).
-constexpr int KB_AB_TAIL_FROM = 4;
+constexpr int KB_AB_TAIL_FROM = 8;
 constexpr int KB_AB_TAIL_ROOTS = 48;
 constexpr int KB_AB_TAIL_WGS = 12;     // workgroups of four wavefronts per member: one root per wavefront
 constexpr int KB_AB_TAIL_MAXC = 8;

@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
 // same order, so the workgroup streams H through LDS in blocks of KB_AB_TAIL_CB columns (double buffered: the global loads
 // of the next block travel under the arithmetic of this one; a step costs no memory latency).  Columns are rescaled by
 // powers of two every 32 steps.  grid (KB_AB_TAIL_WGS, members), 256 threads; dynamic LDS: ab_tail_lds_bytes(lmax).
-constexpr int KB_AB_TAIL_CB = 8;
+constexpr int KB_AB_TAIL_CB = 4;
 constexpr int KB_AB_TAIL_NREG = KB_AB_TAIL_CB * KB_AB_TAIL_MAXL / 256;      // elements of a block per thread
 // element i of a thread's share of a block: column i mod CB, row t + 256 (i / CB) - no divisions, coalesced along the rows
 #define KB_TAIL_LOAD(B_)                                                                                   \

@@ -288,13 +288,18 @@ class Engine:
         self.in_flight = max(1, int(os.environ.get("KBDM_IN_FLIGHT", "4") if in_flight is None else in_flight))
         self._lock = threading.RLock()
         self._wide = None
+        self.wide_solve = os.environ.get("KBDM_WIDE_SOLVE", "1") != "0"   # synchronous batches on the context with panel teams
+        # The runtime hands out its hardware queues (GPU_MAX_HW_QUEUES, 16 asked for by the package) in order of stream
+        # creation and streams that share one serialise: the wide context (three lanes + a side stream) comes first, then
+        # the pool's contexts (three streams each) - a fifth context created late would run its lanes one after the other.
+        if self.wide_solve:
+            self._wide_slot()
         self._slots = [_Slot(self._new_ctx())]
         self.ctx = self._slots[0].ctx
         self._seq = 0
         self._burst = 0
         self._last = None
         self.stagger = os.environ.get("KBDM_STAGGER", "1") != "0"
-        self.wide_solve = os.environ.get("KBDM_WIDE_SOLVE", "1") != "0"   # synchronous batches on the context with panel teams
         # Plans of recent batches, keyed on the batch geometry: a plan owns its device workspace (about 1 GB for a C2
         # ensemble, up to the 96 GiB workspace budget for a C4-sized one), and callers such as `sample_kbdm` /
         # `iterative_llc_kbdm` solve the same geometry again and again with new signals.  The cache is bounded by
@@ -303,13 +308,9 @@ class Engine:
         self.plan_cache_size = int(os.environ.get("KBDM_PLAN_CACHE", "4"))       # plans per context
 
     def _new_ctx(self):
-        """A context of the pool.  KBDM_LANES_FIRST=3 gives the FIRST context - the one a synchronous call (`solve`: kbdm,
-        sample_kbdm, llc_kbdm) runs on - three lanes: 4 % less latency for one ensemble alone (C2: 2770 against 2658 solves/s),
-        2 % less throughput with four ensembles in flight (4420 against 4500), so it is opt-in.  Results do not depend on it."""
+        """A context of the in-flight pool (two lanes, no panel teams; KBDM_LANES / KBDM_PANEL_* are read by the library)."""
         h = _lib.c_void_p()
-        first = not getattr(self, "_slots", None)
-        lanes = int(os.environ.get("KBDM_LANES_FIRST", "0")) if first else 0
-        _lib.check(self.lib.kbdm_ctx_create_lanes(self.device, lanes, h))
+        _lib.check(self.lib.kbdm_ctx_create_lanes(self.device, 0, h))
         return h
 
     # Cooperative panels (include/kbdm_hip.h: kbdm_ctx_set_panel_teams).  The workgroups of a team wait for each other, so

@@ -2,9 +2,9 @@
 # per-kernel VALU instructions / wave cycles / CU-busy (one ensemble at a time) + summary
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rm -rf $OUT/occ
-timeout -k 10 400 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/occ -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > /dev/null 2> $OUT/occ.log
+timeout -k 10 400 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/occ -- python3 $ROOT/bench.py --steps 2 --warmup 1 --trace-mode --in-flight 1 > /dev/null 2> $OUT/occ.log
 rm -rf $OUT/occ2
-timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/occ2 -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > /dev/null 2> $OUT/occ2.log
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/occ2 -- python3 $ROOT/bench.py --steps 2 --warmup 1 --trace-mode --in-flight 1 > /dev/null 2> $OUT/occ2.log
 cd $ROOT
 python3 - <<'PY' | tee $OUT/occ_summary.txt
 import csv, glob, collections
