@@ -18,13 +18,21 @@ The control plane (rank 0's communicator id, barrier, max over ranks) is llckbdm
 socket per rank, standard library only.  `python bench.py --gpus N` without a launcher starts its own ranks.
 
 The JSON line also carries
-  roofline     : the dominant kernel's algorithmic FP64 flops / its HIP-event duration (events recorded by the library
-                 on the stream the kernel runs on) vs the FP64 peak (flop model: SURVEY.md 8d, stated in DESIGN.md)
+  roofline     : the dominant KERNEL of a clean pass (one ensemble at a time, the GPU to itself): its algorithmic bytes or FP64
+                 flops per launch / its average launch duration, from HIP events the library records around every launch on the
+                 stream the kernel runs on (KBDM_MODE_KERNEL_TIMERS); + `top_kernels`, `top_stages`, `north_star` (MFMA
+                 utilisation of the SVD panel update and of the Hessenberg update over all launches, Hankel GB/s) and
+                 `whole_pipeline` (216 m^3 per member, SURVEY.md 8d, over the timed region)
+  value_host_to_host / host_to_host : the same loop with the upload of the signals inside it (SURVEY.md 8d's unit)
+  one_ensemble_at_a_time, sample_kbdm_call, llc_kbdm_c2 : ONE ensemble at a time on the engine's context for synchronous
+                 calls (panel teams), the same through llckbdm_amd.sampling.sample_kbdm, and llc_kbdm end to end
   cpu_baseline : the numpy/scipy oracle (the reference's own LAPACK calls) timed on the host cores of this box on a
-                 bounded sample of the same workload (rank 0, N=1 only): one process per core (best effort) and, as
-                 `serial`, the shape the reference ships (sampling.py:52-62: one loop, default BLAS threads).
+                 bounded sample of the same workload (rank 0, N=1 only): one process per core on EVERY core of the box (and,
+                 as `host_share_16_cores`, on the 16-core share of one GPU), and, as `serial`, the shape the reference ships
+                 (sampling.py:52-62: one loop, default BLAS threads); the CPU model is stated.
   other_configs: short runs of the other BASELINE.json configurations (C3, C4, C5) and of the north-star ensemble
                  m = 100..500 through the same public API (N=1 only).
+--trace-mode (rocprofv3 runs): every ensemble of the process runs in flight, nothing else runs.
 """
 import argparse
 import json

@@ -75,6 +75,7 @@ struct AbWs {
     cd* z[2];
     double* lastc;
     int* conv[2];
+    int* nact;          // unsettled roots of the root node as k_ab_iter counted them in its last launch (read by k_ab_tail)
     cd* panel;
 };
 KB_HD long long ab_ws_doubles(int l) {
@@ -87,6 +88,7 @@ KB_HD AbWs ab_ws(double* base, int l) {
     w.lastc = base + 4 * (size_t)l;
     w.conv[0] = reinterpret_cast<int*>(w.lastc + l);
     w.conv[1] = w.conv[0] + l;
+    w.nact = reinterpret_cast<int*>(base + 6 * (size_t)l);        // (the 16 spare doubles in front of the panels)
     w.panel = reinterpret_cast<cd*>(base + ((6 * (size_t)l + 16 + 1) & ~(size_t)1));
     return w;
 }

@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
         }
     __syncthreads();
     const int nactive = L.flags[0];
+    if (depth == 0 && tile == 0 && t == 0) *ws.nact = nactive;         // (k_ab_tail's workgroups decide on it without a scan)
     if (tail_on && ab_tail_takes(l, depth, iter, nactive)) return;     // the few roots left get a wavefront each (k_ab_tail)
     const int nr = (nactive - tile * KB_AB_TILE < KB_AB_TILE) ? nactive - tile * KB_AB_TILE : KB_AB_TILE;
     if (nr <= 0) return;                                    // this tile has nothing left to iterate
@@ -675,12 +676,14 @@ __global__ void __launch_bounds__(256) k_ab_tail(const kb::KbItem* __restrict__ 
     const int l = it.l, depth = ab_depth(l) - 1 - step;
     if (depth != 0 || l > KB_AB_TAIL_MAXL || iter < KB_AB_TAIL_FROM) return;
     const int n = l;
+    const AbWs ws = ab_item_ws(it, dcarena);
+    // k_ab_iter (launched just before, same iteration) left the number of unsettled roots: most workgroups end here
+    if (!ab_tail_takes(l, depth, iter, *ws.nact) || (int)blockIdx.x * 4 >= *ws.nact) return;
     __shared__ int s_cnt[256];
     __shared__ int s_ridx[KB_AB_TAIL_ROOTS];
     __shared__ int s_nact;
     cd* inv = reinterpret_cast<cd*>(kb_smem);                // 1 / H[k, k-1]
     cd* colbuf = inv + npad;                                 // two blocks of CB columns x npad rows
-    const AbWs ws = ab_item_ws(it, dcarena);
     const int bin = (step * KB_AB_BUDGET + iter) & 1;
     const cd* zin = ws.z[bin];
     cd* zout = ws.z[bin ^ 1];

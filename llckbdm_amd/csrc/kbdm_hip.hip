@@ -404,7 +404,9 @@ int panel_team_size(const kbdm_plan* pl, const Chunk& ch) {
     if (pl->mode & KBDM_MODE_SOLO_QR) return 1;
     if (ch.lane != 0 && !ctx->panel_T_all) return 1;
     int T = std::max(1, ctx->panel_T);
-    while (T > 1 && (long long)((ch.count + 7) / 8 * 8) * T > ctx->panel_budget) --T;
+    // (teams on every lane: the lanes' launches run at the same time and share the budget)
+    const int budget = ctx->panel_T_all ? ctx->panel_budget / std::max(1, ctx->nlanes) : ctx->panel_budget;
+    while (T > 1 && (long long)((ch.count + 7) / 8 * 8) * T > budget) --T;
     return T;
 }
 // rows of the row-product partial sums that fit the LDS next to the other scratch (a multiple of 64; 0: nothing fits)
