@@ -68,186 +68,7 @@ KB_HD cd hess_vt(const cd* W, int ld, int p0, int r, int t) {
     const int kt = p0 + t;
     return (r > kt + 1) ? W[r + (size_t)kt * ld] : ((r == kt + 1) ? mk(1.0, 0.0) : czero());
 }
-KB_HD int hess_panel_scratch_bytes(int n, int nwaves, int ws) {
-    int z = n > nwaves * ws ? n : nwaves * ws;
-    return (n + z + 4 * n + 2 * KB_NB + KB_NB * KB_NB + 8) * (int)sizeof(cd);
-}
-
-template <class C>
-KB_HD void hess_panel(const C& ctx, int N, cd* W, int ld, int p0, cd* tauh, cd* Y, int ldy, cd* VT, int ldvt,
-                      cd* MT) {
-#define W_(r_, c_) W[(r_) + (size_t)(c_) * ld]
-#define Y_(r_, c_) Y[(r_) + (size_t)(c_) * ldy]
-#define T_(r_, c_) Tm[(r_) + (c_) * KB_NB]
-    const int tid = ctx.tid(), nt = ctx.nthreads(), lane = ctx.lane();
-    cd* ub = reinterpret_cast<cd*>(ctx.scratch());           // v (indexed by global row)
-    cd* zp = ub + N;
-    const int zcap = N > ctx.nwaves() * C::WS ? N : ctx.nwaves() * C::WS;
-    cd* sp = zp + zcap;                                      // partial sums of the "skinny" sweeps: 4 N entries
-    cd* w1 = sp + 4 * N;                                     // V^H v  /  V^H x
-    cd* w2 = w1 + KB_NB;                                     // T^H (V^H x)
-    cd* Tm = w2 + KB_NB;                                     // T, NB x NB upper triangular
-    // sweeps with fewer rows than threads: two thread groups split the columns t so far (see bidiag_panel)
-    const int G = (2 * N <= nt) ? 2 : 1;
-    const int gsz = nt / G;
-    const int g = tid / gsz, gi = tid - g * gsz;
-    for (int idx = tid; idx < KB_NB * KB_NB; idx += nt) Tm[idx] = czero();
-    ctx.sync();
-    for (int j = 0; j < KB_NB; ++j) {
-        const int k = p0 + j;
-        // ---- 1a. x = A0(:, k) - Y_j V_j(k, :)^H, all rows: formed by the last sweep of column j - 1 (step 4 below)
-        if (j > 0) {
-            // ---- 1b. w1 = V_j^H x (one wavefront per dot product), w2 = T_j^H w1, x -= V_j w2
-            for (int t = ctx.wave(); t < j; t += ctx.nwaves()) {
-                cd acc = czero();
-                for (int r = p0 + t + 1 + lane; r < N; r += C::WS) cfmac(acc, hess_vt(W, ld, p0, r, t), W_(r, k));
-                acc = ctx.wave_sum(acc);
-                if (lane == 0) w1[t] = acc;
-            }
-            ctx.sync();
-            for (int t = tid; t < j; t += nt) {
-                cd acc = czero();
-                for (int s2 = 0; s2 <= t; ++s2) cfmac(acc, T_(s2, t), w1[s2]);    // (T^H w1)_t = sum_s conj(T(s,t)) w1_s
-                w2[t] = acc;
-            }
-            ctx.sync();
-            for (int r = p0 + 1 + gi; r < N; r += gsz) {
-                cd acc = czero();
-                for (int t = g; t < j; t += G) acc = acc + hess_vt(W, ld, p0, r, t) * w2[t];
-                sp[g * N + r] = acc;
-            }
-            ctx.sync();
-            for (int r = p0 + 1 + tid; r < N; r += nt) {
-                cd acc = sp[r];
-                if (G == 2) acc = acc + sp[N + r];
-                W_(r, k) = W_(r, k) - acc;
-            }
-            ctx.sync();
-        }
-        // ---- 2. reflector from rows k+1..N-1
-        double beta;
-        cd tau;
-        larfg(ctx, N - k - 1, &W_(k + 1, k), beta, tau);
-        ctx.sync();
-        for (int r = k + 1 + tid; r < N; r += nt) ub[r] = (r == k + 1) ? mk(1.0, 0.0) : W_(r, k);
-        ctx.sync();
-        if (tid == 0) { tauh[j] = tau; W_(k + 1, k) = mk(beta, 0.0); }
-        // ---- 3. w1 = V_j^H v  and, in the same phase,
-        // ---- 4. y = tau (A0[:, k+1:] v - Y_j w1), all rows: the one pass over A0 of this column
-        for (int t = ctx.wave(); t < j; t += ctx.nwaves()) {
-            cd acc = czero();
-            for (int r = k + 1 + lane; r < N; r += C::WS) cfmac(acc, hess_vt(W, ld, p0, r, t), ub[r]);
-            acc = ctx.wave_sum(acc);
-            if (lane == 0) w1[t] = acc;
-        }
-        {
-            const int ncols = N - k - 1;
-            const int nw = ctx.nwaves();
-            const int nrc = (N + C::WS - 1) / C::WS;
-            const int ncg = (nrc >= nw) ? 1 : (nw / nrc);
-            const int nslots = nrc * ncg;
-            const cd* Ab = &W_(0, k + 1);
-            for (int slot = ctx.wave(); slot < nslots; slot += nw) {
-                const int rc = slot % nrc, cg = slot / nrc;
-                const int i = rc * C::WS + lane;
-                if (i < N) {
-                    cd acc = czero(), acc1 = czero(), acc2 = czero(), acc3 = czero();
-                    int c = cg;
-                    for (; c + 3 * ncg < ncols; c += 4 * ncg) {
-                        const cd a0 = Ab[i + (size_t)c * ld], a1 = Ab[i + (size_t)(c + ncg) * ld];
-                        const cd a2 = Ab[i + (size_t)(c + 2 * ncg) * ld], a3 = Ab[i + (size_t)(c + 3 * ncg) * ld];
-                        cfma(acc, a0, ub[k + 1 + c]); cfma(acc1, a1, ub[k + 1 + c + ncg]);
-                        cfma(acc2, a2, ub[k + 1 + c + 2 * ncg]); cfma(acc3, a3, ub[k + 1 + c + 3 * ncg]);
-                    }
-                    for (; c < ncols; c += ncg) cfma(acc, Ab[i + (size_t)c * ld], ub[k + 1 + c]);
-                    zp[cg * N + i] = (acc + acc1) + (acc2 + acc3);
-                }
-            }
-            ctx.sync();
-            // the corrections of y with Y_j w1 and - same rows, same columns of Y - column k + 1 of A0 - Y_{j+1} V_{j+1}(k+1, :)^H
-            // for the next step (one sweep instead of two)
-            const bool nextcol = j + 1 < KB_NB;
-            for (int r = gi; r < N; r += gsz) {
-                cd hp = czero(), np = czero();
-                for (int t = g; t < j; t += G) {
-                    const cd yrt = Y_(r, t);
-                    hp = hp + yrt * w1[t];
-                    if (nextcol) np = np + yrt * conj(hess_vt(W, ld, p0, k + 1, t));
-                }
-                sp[(0 * G + g) * N + r] = hp;
-                sp[(1 * G + g) * N + r] = np;
-            }
-            ctx.sync();
-            for (int r = tid; r < N; r += nt) {
-                cd h = czero();
-                for (int gz = 0; gz < ncg; ++gz) h += zp[gz * N + r];
-                cd hp = sp[r], np = sp[G * N + r];
-                if (G == 2) { hp = hp + sp[N + r]; np = np + sp[3 * N + r]; }
-                const cd y = tau * (h - hp);
-                Y_(r, j) = y;
-                if (nextcol) W_(r, k + 1) = (W_(r, k + 1) - np) - y;            // ... - Y(r, j) conj(V(k+1, j)), V(k+1, j) = 1
-            }
-        }
-        // ---- 5. T(0:j, j) = -tau T_j w1, T(j, j) = tau
-        for (int t = tid; t <= j; t += nt) {
-            if (t == j) T_(j, j) = tau;
-            else {
-                cd acc = czero();
-                for (int s2 = t; s2 < j; ++s2) cfma(acc, T_(t, s2), w1[s2]);
-                T_(t, j) = -(tau * acc);
-            }
-        }
-        ctx.sync();
-    }
-    // ---- VT = V T (all rows; rows <= p0 are zero) and MT = (Y^H V) T for the deferred left factor
-    for (int idx = tid; idx < N * 2; idx += nt) {             // two threads per row: the even / the odd columns t
-        const int r = idx >> 1, half = idx & 1;
-        cd acc[KB_NB / 2];
-#pragma unroll
-        for (int q = 0; q < KB_NB / 2; ++q) acc[q] = czero();
-        for (int s2 = 0; s2 < KB_NB; ++s2) {                  // T is upper triangular with explicit zeros below
-            const cd v = hess_vt(W, ld, p0, r, s2);
-#pragma unroll
-            for (int q = 0; q < KB_NB / 2; ++q) cfma(acc[q], v, T_(s2, 2 * q + half));
-        }
-#pragma unroll
-        for (int q = 0; q < KB_NB / 2; ++q) VT[r + (size_t)(2 * q + half) * ldvt] = acc[q];
-    }
-    ctx.sync();
-    // (Y^H V T)(u, t) = sum_r conj(Y(r,u)) VT(r,t): one thread per entry, the rows staged through LDS in slabs
-    // (sp: 4 N entries = slabs of 2 N / NB rows of Y and of VT)
-    {
-        const int slab = (2 * N / KB_NB) < 1 ? 1 : (2 * N / KB_NB);     // rows per slab: slab * NB entries each for Y and VT
-        cd* sy = sp;
-        cd* sv = sp + (size_t)slab * KB_NB;
-        const int u = tid % KB_NB, t = tid / KB_NB;                     // entry of this thread (tid < NB * NB)
-        cd acc = czero();
-        for (int r0 = p0 + 1; r0 < N; r0 += slab) {
-            const int rows = (N - r0 < slab) ? N - r0 : slab;
-            for (int idx = tid; idx < rows * KB_NB; idx += nt) {
-                const int rr = idx % rows, cc = idx / rows;
-                sy[rr + cc * slab] = Y_(r0 + rr, cc);
-                sv[rr + cc * slab] = VT[(r0 + rr) + (size_t)cc * ldvt];
-            }
-            ctx.sync();
-            if (tid < KB_NB * KB_NB)
-                for (int rr = 0; rr < rows; ++rr) cfmac(acc, sy[rr + u * slab], sv[rr + t * slab]);
-            ctx.sync();
-        }
-        if (tid < KB_NB * KB_NB) MT[u + t * KB_NB] = acc;
-        // (fewer threads than entries - the host simulation - : the remaining entries)
-        for (int e = tid + nt; e < KB_NB * KB_NB; e += nt) {
-            const int uu = e % KB_NB, tt = e / KB_NB;
-            cd a2 = czero();
-            for (int r = p0 + 1; r < N; ++r) cfmac(a2, Y_(r, uu), VT[r + (size_t)tt * ldvt]);
-            MT[uu + tt * KB_NB] = a2;
-        }
-    }
-    ctx.sync();
-#undef W_
-#undef Y_
-#undef T_
-}
+// (the panel itself: kb_panel_team.hpp, hess_panel_team - teams of T >= 1 workgroups per member)
 
 // Deferred left factor of one panel for the trailing columns c in [c_begin, c_end):
 //   Z(c, t) = sum_r conj(A0(r, c)) VT(r, t) - sum_u V(c, u) MT(u, t)          (reference form; the device kernel

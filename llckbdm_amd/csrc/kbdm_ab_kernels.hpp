@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(256) k_ab_iter(const kb::KbItem* __restrict__ 
 constexpr int KB_AB_TAIL_CB = 4;
 constexpr int KB_AB_TAIL_NREG = KB_AB_TAIL_CB * KB_AB_TAIL_MAXL / 256;      // elements of a block per thread
 // element i of a thread's share of a block: column i mod CB, row t + 256 (i / CB) - no divisions, coalesced along the rows
-#define KB_TAIL_LOAD(B_)                                                                                   \
+#define KB_TAIL_LOAD(B_, regs)                                                                                \
     {                                                                                                      \
         const int rows_ = (CB * (B_) + CB < n) ? CB * (B_) + CB : n;                                       \
         _Pragma("unroll") for (int i = 0; i < KB_AB_TAIL_NREG; ++i) {                                      \
@@ -600,7 +600,7 @@ constexpr int KB_AB_TAIL_NREG = KB_AB_TAIL_CB * KB_AB_TAIL_MAXL / 256;      // e
             regs[i] = (r_ < rows_ && j_ < n) ? H[r_ + (size_t)j_ * l] : kb::czero();                       \
         }                                                                                                  \
     }
-#define KB_TAIL_STORE(B_, buf_)                                                                            \
+#define KB_TAIL_STORE(B_, buf_, regs)                                                                        \
     {                                                                                                      \
         const int rows_ = (CB * (B_) + CB < n) ? CB * (B_) + CB : n;                                       \
         _Pragma("unroll") for (int i = 0; i < KB_AB_TAIL_NREG; ++i) {                                      \
@@ -612,56 +612,65 @@ constexpr int KB_AB_TAIL_NREG = KB_AB_TAIL_CB * KB_AB_TAIL_MAXL / 256;      // e
 // into the register arrays is a compile-time constant.
 template <int CJ>
 __device__ __forceinline__ void ab_tail_chunk(kb::cd& sx_, kb::cd& sy_, kb::cd& srho_, kb::cd& srhop_, int& scur_, kb::cd (&Sx)[KB_AB_TAIL_MAXC], kb::cd (&Sy)[KB_AB_TAIL_MAXC],
-                                              kb::cd (&regs)[KB_AB_TAIL_NREG], const kb::cd* __restrict__ H, int l, int n, int npad,
+                                              kb::cd (&regs0)[KB_AB_TAIL_NREG], kb::cd (&regs1)[KB_AB_TAIL_NREG], const kb::cd* __restrict__ H, int l, int n, int npad,
                                               int Bmax, int t, int lane, bool act, kb::cd z, const kb::cd* inv, kb::cd* colbuf) {
     using namespace kb;
     constexpr int MAXC = KB_AB_TAIL_MAXC, CB = KB_AB_TAIL_CB;
     if (CJ * 64 >= n) return;
     const int Bhi = (CJ * (64 / CB) + (64 / CB) - 1 < Bmax) ? CJ * (64 / CB) + (64 / CB) - 1 : Bmax;
-    for (int B = Bhi; B >= CJ * (64 / CB); --B) {
-        if (B > 0) KB_TAIL_LOAD(B - 1)                       // in flight under this block's arithmetic
-        const cd* buf = colbuf + (size_t)scur_ * CB * npad;
-        if (act) {
-#pragma unroll
-            for (int jj = CB - 1; jj >= 0; --jj) {
-                const int j = CB * B + jj;
-                if (j >= n) continue;
-                const int p = j & 63;
-#pragma unroll
-                for (int c = 0; c <= CJ; ++c) {
-                    const int r = lane + 64 * c;
-                    const cd h = (r <= j) ? buf[jj * npad + r] : czero();
-                    cfma(Sx[c], h, sx_); cfma(Sy[c], h, sy_);
-                }
-                // row j is complete
-                const cd sj = mk(DevCtx::lane_f64(Sx[CJ].x, p), DevCtx::lane_f64(Sx[CJ].y, p));
-                const cd spj = mk(DevCtx::lane_f64(Sy[CJ].x, p), DevCtx::lane_f64(Sy[CJ].y, p));
-                const cd s = sj - z * sx_;
-                const cd sp = (spj - z * sy_) - sx_;
-                if (j > 0) {
-                    const cd iv = inv[j];
-                    sx_ = -(s * iv);
-                    sy_ = -(sp * iv);
-                    if (((n - j) & 31) == 0) {                     // rescale by a power of two (only rho / rho' is used)
-                        const double mx = fmax(fabs(sx_.x), fabs(sx_.y));
-                        int e = 0;
-                        if (mx > 0.0 && mx == mx && mx < 1.79769313486231570815e308) (void)frexp(mx, &e);
-                        if (e > 60 || e < -60) {
-                            const double f = ldexp(1.0, -e);
-                            sx_ = f * sx_; sy_ = f * sy_;
-#pragma unroll
-                            for (int c = 0; c < MAXC; ++c) { Sx[c] = f * Sx[c]; Sy[c] = f * Sy[c]; }
-                        }
-                    }
-                } else {
-                    srho_ = s; srhop_ = sp;
-                }
-            }
-        }
-        if (B > 0) KB_TAIL_STORE(B - 1, colbuf + (size_t)(scur_ ^ 1) * CB * npad)
-        __syncthreads();
-        scur_ ^= 1;
+    const int Blo = CJ * (64 / CB);                          // (even)
+    // One block: two blocks of loads are in flight in the registers (block B - 1 since the last iteration, block B - 2 from now
+    // on); RL_ / RS_ = the register set that takes block B - 2 / that holds block B - 1 - fixed by the parity of B, which the
+    // loop below keeps static (a set chosen at run time would send both arrays to scratch).
+#define KB_TAIL_BODY(B, RL_, RS_)                                                                              \
+    {                                                                                                          \
+        if ((B) > 1) KB_TAIL_LOAD((B) - 2, RL_)                                                                \
+        const cd* buf = colbuf + (size_t)scur_ * CB * npad;                                                    \
+        if (act) {                                                                                             \
+            _Pragma("unroll") for (int jj = CB - 1; jj >= 0; --jj) {                                           \
+                const int j = CB * (B) + jj;                                                                   \
+                if (j >= n) continue;                                                                          \
+                const int p = j & 63;                                                                          \
+                _Pragma("unroll") for (int c = 0; c <= CJ; ++c) {                                              \
+                    const int r = lane + 64 * c;                                                               \
+                    const cd h = (r <= j) ? buf[jj * npad + r] : czero();                                      \
+                    cfma(Sx[c], h, sx_); cfma(Sy[c], h, sy_);                                                  \
+                }                                                                                              \
+                const cd sj = mk(DevCtx::lane_f64(Sx[CJ].x, p), DevCtx::lane_f64(Sx[CJ].y, p));                \
+                const cd spj = mk(DevCtx::lane_f64(Sy[CJ].x, p), DevCtx::lane_f64(Sy[CJ].y, p));               \
+                const cd s = sj - z * sx_;                                                                     \
+                const cd sp = (spj - z * sy_) - sx_;                                                           \
+                if (j > 0) {                                                                                   \
+                    const cd iv = inv[j];                                                                      \
+                    sx_ = -(s * iv);                                                                           \
+                    sy_ = -(sp * iv);                                                                          \
+                    if (((n - j) & 31) == 0) {                                                                 \
+                        const double mx = fmax(fabs(sx_.x), fabs(sx_.y));                                      \
+                        int e = 0;                                                                             \
+                        if (mx > 0.0 && mx == mx && mx < 1.79769313486231570815e308) (void)frexp(mx, &e);      \
+                        if (e > 60 || e < -60) {                                                               \
+                            const double f = ldexp(1.0, -e);                                                   \
+                            sx_ = f * sx_; sy_ = f * sy_;                                                      \
+                            _Pragma("unroll") for (int c = 0; c < MAXC; ++c) { Sx[c] = f * Sx[c]; Sy[c] = f * Sy[c]; } \
+                        }                                                                                      \
+                    }                                                                                          \
+                } else {                                                                                       \
+                    srho_ = s; srhop_ = sp;                                                                    \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        if ((B) > 0) KB_TAIL_STORE((B) - 1, colbuf + (size_t)(scur_ ^ 1) * CB * npad, RS_)                     \
+        __syncthreads();                                                                                       \
+        scur_ ^= 1;                                                                                            \
     }
+    // even B: block B - 2 (even) -> regs0, block B - 1 (odd) <- regs1;  odd B: the other way round
+    int B = Bhi;
+    if (!(B & 1) && B >= Blo) { KB_TAIL_BODY(B, regs0, regs1) --B; }
+    for (; B > Blo; B -= 2) {
+        KB_TAIL_BODY(B, regs1, regs0)
+        KB_TAIL_BODY(B - 1, regs0, regs1)
+    }
+#undef KB_TAIL_BODY
 }
 KB_HD int ab_tail_npad(int l) { return (l + 63) & ~63; }
 KB_HD int ab_tail_lds_bytes(int l) { return (1 + 2 * KB_AB_TAIL_CB) * ab_tail_npad(l) * (int)sizeof(kb::cd); }
@@ -720,9 +729,10 @@ __global__ void __launch_bounds__(256) k_ab_tail(const kb::KbItem* __restrict__ 
     const bool act = q < nactive;                            // (wavefront-uniform)
     // block B = columns CB B .. CB B + CB - 1 (< n), rows 0 .. rows(B) - 1
     const int Bmax = (n - 1) / CB;
-    cd regs[KB_AB_TAIL_NREG];
-    KB_TAIL_LOAD(Bmax)
-    KB_TAIL_STORE(Bmax, colbuf)
+    cd regs0[KB_AB_TAIL_NREG], regs1[KB_AB_TAIL_NREG];
+    KB_TAIL_LOAD(Bmax, regs0)
+    KB_TAIL_STORE(Bmax, colbuf, regs0)
+    if (Bmax > 0) { if ((Bmax - 1) & 1) KB_TAIL_LOAD(Bmax - 1, regs1) else KB_TAIL_LOAD(Bmax - 1, regs0) }
     __syncthreads();                                         // (also: s_ridx, inv)
     int me = 0;
     cd z = czero(), S = czero();
@@ -749,14 +759,14 @@ __global__ void __launch_bounds__(256) k_ab_tail(const kb::KbItem* __restrict__ 
     for (int c = 0; c < MAXC; ++c) { Sx[c] = czero(); Sy[c] = czero(); }
     cd x = mk(1.0, 0.0), y = czero(), rho = czero(), rhop = czero();
     int cur = 0;
-    ab_tail_chunk<7>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
-    ab_tail_chunk<6>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
-    ab_tail_chunk<5>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
-    ab_tail_chunk<4>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
-    ab_tail_chunk<3>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
-    ab_tail_chunk<2>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
-    ab_tail_chunk<1>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
-    ab_tail_chunk<0>(x, y, rho, rhop, cur, Sx, Sy, regs, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<7>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<6>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<5>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<4>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<3>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<2>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<1>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
+    ab_tail_chunk<0>(x, y, rho, rhop, cur, Sx, Sy, regs0, regs1, H, l, n, npad, Bmax, t, lane, act, z, inv, colbuf);
     if (act && lane == 0) {
         double dz;
         const cd zn = ab_update(z, rho, rhop, S, &dz);

@@ -115,7 +115,6 @@ struct kbdm_ctx {
                           // 0 = one workgroup per member, N = fixed
     int gen_wy = 1;       // explicit Q / P / Qh of large members by blocked compact-WY accumulation on MFMA (0: k_gen for all)
     int blocked = 1;      // blocked (panel + MFMA update) reductions; 0: unblocked kernels only (debugging)
-    int bidiag_fused = 0; // KBDM_BIDIAG_FUSED=1: one pass over the trailing matrix per panel column (members up to 512 rows)
     int hqr_prof = 0;     // KBDM_HQR_PROF: cycle-counter dump of the QR iteration (diagnostic, synchronous)
     int nb_hqr2 = 8;      // bulges in flight (two shifts each) of the second-generation iteration
     int win_hqr2 = KB2_WIN_DEV;   // its LDS window (fixed: the device chase is compiled for it)
@@ -126,7 +125,6 @@ struct kbdm_ctx {
     int panel_budget = 64;    // ... as long as all teams of the launch fit this many workgroups (they wait for each other, so
                           // they must all be resident: the sum over the contexts of a process must stay below the CU count)
     int panel_T_all = 0;  // KBDM_PANEL_T_ALL=1: teams on every lane (the budget then counts per lane)
-    int panel_old = 0;    // KBDM_PANEL_OLD=1: the round-3 one-workgroup panels (A/B)
     int ab_tail = 1;      // the root level's tail on the wavefront-per-root kernel (KBDM_AB_TAIL=0: tile kernel throughout)
     int ab_dbg = 0;       // KBDM_AB_DBG, read once when the context is created: 8 = phase timers of k_ab_iter (tools/ab_phases.py);
                           // the bits that skip work (2, 4: timing experiments, wrong results) exist in -DKBDM_DEBUG_BUILD libraries only
@@ -207,15 +205,12 @@ size_t item_arena_elems(int m, int l) {
 
 int set_lds_attr() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_svd_fac), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_setup), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_iter), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ab_tail), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 2048));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_tfac), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wy_apply), hipFuncAttributeMaxDynamicSharedMemorySize, KB_WY_APPLY_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bidiag_panel_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hess_panel_team), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hqr2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
@@ -527,27 +522,15 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     {
         // blocked part: panels + MFMA trailing updates (all inside the "k_svd_fac" stage timer)
         const int npan = ctx->blocked ? bidiag_num_panels(ch.mmax) : 0;
-        int smp = KB_RED_BYTES + bidiag_panel_scratch_bytes(ch.mmax, ctx->nt_fac / 64, 64);
-        // one-pass panels (bidiag_panel_fused): a column in 8 register chunks and nwaves row accumulators in LDS
-        const int smf = KB_RED_BYTES + bidiag_panel_fused_scratch_bytes(ch.mmax, KB_PANEL_FUSED_NT / 64);
-        const int fused = (ctx->bidiag_fused && ch.mmax <= KB_PANEL_FUSED_MAXC * 64 && smf <= LDS_MAX) ? 1 : 0;
-        if (npan > 0 && ctx->panel_old && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
-        const int oldp = ctx->panel_old;
         const int T = panel_team_size(pl, ch);
         const int zr = panel_team_zr(ch.mmax, ctx->nt_fac);
         const int smt = KB_RED_BYTES + panel_team_scratch_bytes(ch.mmax, zr, ctx->nt_fac);
-        if (npan > 0 && !fused && !oldp) {
+        if (npan > 0) {
             if (zr < 64) return fail(KBDM_E_NOMEM, "m too large for the panel scratch");
             HIPCHK(hipMemsetAsync(pl->d_pteam + ch.first, 0, sizeof(PanelTeamCtl) * ch.count, st));
         }
         for (int pnl = 0; pnl < npan; ++pnl) {
-            if (fused)
-                hipLaunchKernelGGL(k_bidiag_panel<1>, dim3(ch.count), dim3(KB_PANEL_FUSED_NT), smf, st, pl->d_items, perm,
-                                   pl->d_arena, pl->d_varena, pnl, smf);
-            else if (oldp)
-                hipLaunchKernelGGL(k_bidiag_panel<0>, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
-                                   pl->d_arena, pl->d_varena, pnl, smp);
-            else {
+            {
                 KBracket kb(pl, ch, KBDM_K_BIDIAG_PANEL, st, 1);
                 hipLaunchKernelGGL(k_bidiag_panel_team, dim3((ch.count + 7) / 8 * 8 * T), dim3(ctx->nt_fac), smt, st, pl->d_items,
                                    perm, pl->d_arena, pl->d_varena, pnl, smt, T, ch.count, pl->d_pteam + ch.first, zr,
@@ -577,21 +560,15 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
     const int* perm = pl->d_perm + ch.first;
     {
         const int npan = ctx->blocked ? bidiag_num_panels(ch.lmax) : 0;
-        const int smp = KB_RED_BYTES + hess_panel_scratch_bytes(ch.lmax, ctx->nt_fac / 64, 64);
-        if (npan > 0 && ctx->panel_old && smp > LDS_MAX) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg panel scratch");
-        const int oldp = ctx->panel_old;
         const int T = panel_team_size(pl, ch);
         const int zr = panel_team_zr(ch.lmax, ctx->nt_fac);
         const int smt = KB_RED_BYTES + panel_team_scratch_bytes(ch.lmax, zr, ctx->nt_fac);
-        if (npan > 0 && !oldp) {
+        if (npan > 0) {
             if (zr < 64) return fail(KBDM_E_NOMEM, "l too large for the Hessenberg panel scratch");
             HIPCHK(hipMemsetAsync(pl->d_pteam + ch.first, 0, sizeof(PanelTeamCtl) * ch.count, st));
         }
         for (int pnl = 0; pnl < npan; ++pnl) {
-            if (oldp)
-                hipLaunchKernelGGL(k_hess_panel, dim3(ch.count), dim3(ctx->nt_fac), smp, st, pl->d_items, perm,
-                                   pl->d_arena, pl->d_varena, pnl, smp);
-            else {
+            {
                 KBracket kb(pl, ch, KBDM_K_HESS_PANEL, st, 1);
                 hipLaunchKernelGGL(k_hess_panel_team, dim3((ch.count + 7) / 8 * 8 * T), dim3(ctx->nt_fac), smt, st, pl->d_items,
                                    perm, pl->d_arena, pl->d_varena, pnl, smt, T, ch.count, pl->d_pteam + ch.first, zr,
@@ -906,11 +883,9 @@ int kbdm_ctx_create_lanes(int device, int nlanes, kbdm_ctx** out) {
     c->gen_wy = env_int("KBDM_GEN_WY", c->gen_wy);
     c->eig_ab = env_int("KBDM_EIG_AB", c->eig_ab);
     c->hqr_prof = env_int("KBDM_HQR_PROF", c->hqr_prof);
-    c->bidiag_fused = env_int("KBDM_BIDIAG_FUSED", c->bidiag_fused);
     c->panel_T = std::min(32, std::max(1, env_int("KBDM_PANEL_T", c->panel_T)));
     c->panel_budget = std::max(8, env_int("KBDM_PANEL_BUDGET", c->panel_budget));
     c->panel_T_all = env_int("KBDM_PANEL_T_ALL", c->panel_T_all);
-    c->panel_old = env_int("KBDM_PANEL_OLD", c->panel_old);
     c->ab_dbg = env_int("KBDM_AB_DBG", 0);
     c->ab_tail = env_int("KBDM_AB_TAIL", c->ab_tail);
 #if !defined(KBDM_DEBUG_BUILD)

@@ -76,35 +76,11 @@ __global__ void __launch_bounds__(256) k_hankel(const KbItem* __restrict__ items
 
 // ------------------------------------------------------------------------------------
 // Householder bidiagonalisation, blocked: for panel p = 0, 1, ... (host loop)
-//   k_bidiag_panel  one workgroup per item: NB reflector pairs, X/Y panels (Q and P buffers are
-//                   free at this point); the two matrix-vector products with the trailing matrix per column
-//                   share ONE pass over it (bidiag_panel_fused) for members of at most 512 rows
+//   k_bidiag_panel_team  a team of T >= 1 workgroups per item: NB reflector pairs, X/Y panels (Q and P buffers are
+//                   free at this point), two matrix-vector products with the trailing matrix per column
 //   k_trail_update  all CUs: A0[NB:, NB:] -= [V | X] [Y | U]^H  with FP64 MFMA 16x16x4 tiles
 // then k_svd_fac finishes the last (< NB + NX) columns unblocked.
 // Left vectors stay in A, right vectors go to the R buffer (free until the sort).
-template <int FUSED>
-__global__ void __launch_bounds__(FUSED ? KB_PANEL_FUSED_NT : 1024) k_bidiag_panel(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                        cd* arena, double* varena, int panel, int smem_bytes) {
-    const KbItem it = items[perm[blockIdx.x]];
-    const int m = it.m;
-    if (panel >= bidiag_num_panels(m)) return;
-    const DevCtx ctx = make_ctx(smem_bytes);
-    const int p0 = panel * KB_NB;
-    cd* A = arena + it.off[KB_BUF_A] + p0 + (size_t)p0 * m;
-    cd* UR = arena + it.off[KB_BUF_R] + p0 + (size_t)p0 * m;
-    cd* X = arena + it.off[KB_BUF_Q];
-    cd* Y = arena + it.off[KB_BUF_P];
-    double* dv = varena + it.voff;
-    double* d = dv + KB_V_D * it.vstride + p0;
-    double* e = dv + KB_V_E * it.vstride + p0;
-    cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride) + p0;
-    cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride) + p0;
-    // FUSED: one pass over the trailing matrix per column (the host launches it when a column fits the register chunks
-    // and sizes the scratch for it)
-    if (FUSED) bidiag_panel_fused<DevCtx, KB_PANEL_FUSED_MAXC>(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
-    else bidiag_panel(ctx, m - p0, A, m, d, e, tauq, taup, UR, m, X, Y, m);
-}
-
 // The panel for a team of T workgroups per member (kb_team.hpp, kb_panel_team.hpp; T = 1: one workgroup, no waiting).
 // grid = 8 * ceil(count / 8) * T: block b belongs to slot b & 7 (blocks of equal slot share an XCD when the dispatcher deals
 // them round robin - faster, never required), within the slot consecutive groups of T blocks are the teams.  `pos0` is the
@@ -604,24 +580,10 @@ __global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, 
 
 // ------------------------------------------------------------------------------------
 // Blocked Hessenberg reduction of W (KB_BUF_P): for panel p = 0, 1, ... (host loop)
-//   k_hess_panel   one workgroup per item: NB reflectors, Y -> KB_BUF_Q; VT, MT -> KB_BUF_H (one pass over A0 per column)
+//   k_hess_panel_team   a team of T >= 1 workgroups per item: NB reflectors, Y -> KB_BUF_Q; VT, MT -> KB_BUF_H (one pass over A0 per column)
 //   k_hess_z       all CUs: Z = A0^H VT - V MT for the columns right of the panel -> KB_BUF_H
 //   k_hess_update  all CUs: W[:, p0+NB:] -= [Y | V] [V | Z]^H  (FP64 MFMA tiles)
 // then k_hess finishes unblocked, extracts the work copy (KB_BUF_H) and ||H||_inf.
-__global__ void __launch_bounds__(1024) k_hess_panel(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                      cd* arena, double* varena, int panel, int smem_bytes) {
-    const KbItem it = items[perm[blockIdx.x]];
-    const int n = it.l;
-    if (panel >= bidiag_num_panels(n)) return;
-    const DevCtx ctx = make_ctx(smem_bytes);
-    const int p0 = panel * KB_NB;
-    cd* W = arena + it.off[KB_BUF_P];
-    cd* Y = arena + it.off[KB_BUF_Q];
-    cd* Z = arena + it.off[KB_BUF_H];          // Z (n x NB), then MT (NB x NB), then VT (n x NB): n >= NB + NX
-    cd* tauh = reinterpret_cast<cd*>(varena + it.voff + KB_V_TAUQ * it.vstride) + p0;
-    hess_panel(ctx, n, W, n, p0, tauh, Y, n, Z + (size_t)n * KB_NB + KB_NB * KB_NB, n, Z + (size_t)n * KB_NB);
-}
-
 __global__ void __launch_bounds__(1024) k_hess_panel_team(const KbItem* __restrict__ items, const int* __restrict__ perm,
                                                            cd* arena, double* varena, int panel, int smem_bytes, int T,
                                                            int count, PanelTeamCtl* ctl, int zr, int* status) {

@@ -71,12 +71,7 @@ static void hs_bidiag_blocked(HostCtx& ctx, int m, cd* A, double* d, double* e, 
         const int p0 = p * KB_NB, n = m - p0;
         cd* Ab = A + p0 + (size_t)p0 * m;
         cd* Ub = UR + p0 + (size_t)p0 * m;
-        // HS_BIDIAG_FUSED=1: the one-pass panel (a knob on the device); HS_BIDIAG_FUSED=0: the round-3 two-pass panel;
-        // default: the team panel the device runs (HS_PANEL_T workgroups per member)
-        const char* fz = getenv("HS_BIDIAG_FUSED");
-        if (fz && atoi(fz) == 0) bidiag_panel(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
-        else if (fz) bidiag_panel_fused<HostCtx, HS_MAXC>(ctx, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m);
-        else
+        // the team panel the device runs (HS_PANEL_T "workgroups" per member)
             hs_run_team(hs_team_size(), panel_team_scratch_bytes(n, HS_ZR, 1), xbuf.data(), [&](HostCtx& c, PanelTeam<HostCtx>& tm) {
                 bidiag_panel_team(c, tm, n, Ab, m, d + p0, e + p0, tq + p0, tp + p0, Ub, m, X.data(), Y.data(), m, HS_ZR);
             });
@@ -145,7 +140,7 @@ int hs_svd(const double* A_in, int m, double* L_out, double* s_out, double* R_ou
     std::vector<double> d(m), e(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1) + 4 * m);
+    HostCtx ctx = make_ctx(arena, panel_team_scratch_bytes(m, HS_ZR, 1) + 4 * m);
     hs_bidiag_blocked(ctx, m, A.data(), d.data(), e.data(), tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), Q.data(), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), P.data(), m, 0, m);
@@ -171,7 +166,7 @@ int hs_bidiag(const double* A_in, int m, double* d, double* e, double* Q_out, do
     std::vector<cd> A(m * m), UR(m * m), tq(m), tp(m);
     memcpy(A.data(), A_in, sizeof(cd) * m * m);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, bidiag_panel_fused_scratch_bytes(m, 1) + bidiag_panel_scratch_bytes(m, 1, 1));
+    HostCtx ctx = make_ctx(arena, panel_team_scratch_bytes(m, HS_ZR, 1));
     hs_bidiag_blocked(ctx, m, A.data(), d, e, tq.data(), tp.data(), UR.data());
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m, 0, A.data(), m, tq.data(), reinterpret_cast<cd*>(Q_out), m, 0, m);
     gen_unitary_cols<HostCtx, HS_MAXC>(ctx, m, m - 1, 1, UR.data(), m, tp.data(), reinterpret_cast<cd*>(P_out), m, 0, m);
@@ -183,15 +178,14 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
     std::vector<cd> W(n * n), Qh(n * n), Hc(n * n), Ht(n * n), X(n * n), th(n);
     memcpy(W.data(), W_in, sizeof(cd) * n * n);
     std::vector<char> arena;
-    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + hess_panel_scratch_bytes(n, 1, 1) + invit_scratch_bytes_per_wave(n) +
+    HostCtx ctx = make_ctx(arena, gehd2_scratch_bytes(n, 1, 1) + panel_team_scratch_bytes(n, HS_ZR, 1) + invit_scratch_bytes_per_wave(n) +
                                       hqr2_scratch_bytes(KB2_WIN_DEV));
     {   // blocked Hessenberg reduction as the kernels sequence it: panels + updates + tail
         const int npan = bidiag_num_panels(n);
         std::vector<cd> Yp((size_t)n * KB_NB), Zp((size_t)n * KB_NB), VTp((size_t)n * KB_NB), MTp(KB_NB * KB_NB);
         for (int pnl = 0; pnl < npan; ++pnl) {
             const int p0 = pnl * KB_NB;
-            if (getenv("HS_HESS_OLD")) hess_panel(ctx, n, W.data(), n, p0, th.data() + p0, Yp.data(), n, VTp.data(), n, MTp.data());
-            else {
+            {
                 std::vector<cd> xbuf((size_t)panel_team_xbuf_elems(n));
                 hs_run_team(hs_team_size(), panel_team_scratch_bytes(n, HS_ZR, 1), xbuf.data(), [&](HostCtx& c, PanelTeam<HostCtx>& tm) {
                     hess_panel_team(c, tm, n, W.data(), n, p0, th.data() + p0, Yp.data(), n, VTp.data(), n, MTp.data(), HS_ZR);

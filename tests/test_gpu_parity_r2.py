@@ -224,34 +224,3 @@ def test_random_ragged_sweep_against_oracle(eng, p, q, bound_strong):
     assert worst_strong <= bound_strong, f"lines with A > 1e-4: {worst_strong:.2e}"
 
 
-def test_one_pass_bidiagonalisation_option_on_the_device(eng):
-    """KBDM_BIDIAG_FUSED=1 (bidiag_panel_fused: one pass over the trailing matrix per panel column) is an option, not the
-    default; it must still be a correct bidiagonalisation: singular values to 1e-14 m s0 of the default path's, the same
-    kept lines, the lines on the true frequencies to 1e-8 of the oracle's."""
-    from llckbdm_amd.engine import Engine
-    sig = O.make_noisy(O.brain_sim_signal(2048), 1e-3, 21)
-    ms = [150, 256, 400]
-    ref = eng.solve(sig.reshape(1, -1), [0] * len(ms), ms, None, p=1, q=0.0, dwell=DWELL)
-    os.environ["KBDM_BIDIAG_FUSED"] = "1"
-    try:
-        e2 = Engine(0)
-        try:
-            got = e2.solve(sig.reshape(1, -1), [0] * len(ms), ms, None, p=1, q=0.0, dwell=DWELL)
-        finally:
-            e2.close()
-    finally:
-        del os.environ["KBDM_BIDIAG_FUSED"]
-    assert not got.status.any()
-    truth = O.brain_sim_params_sorted()
-    for i, m in enumerate(ms):
-        s0 = ref.singular_values(i)[0]
-        assert np.abs(got.singular_values(i) - ref.singular_values(i)).max() < 1e-14 * m * s0
-        a, b = got.line_list(i), ref.line_list(i)
-        ka, kb = canonical(a[keep_mask(a)]), canonical(b[keep_mask(b)])
-        assert len(ka) == len(kb)
-        want, _ = O.kbdm(sig, DWELL, m=m, normalizer="gemm")
-        w = canonical(O.filter_samples(want))
-        assert len(w) == len(ka)
-        rows = resolved_genuine_rows(w, truth)
-        assert len(rows) >= 14
-        assert_lines_close(ka[rows], w[rows], rel=1e-8, phase_abs=1e-8, what=f"fused panel, m={m}")

@@ -189,30 +189,6 @@ def test_second_generation_qr_iteration_host_form(hs):
     assert np.abs(mu[:, None] - ref[None, :]).min(axis=1).max() < 1e-11 * np.abs(ref).max() * m
 
 
-def test_one_pass_bidiagonalisation_panel_matches_two_pass(hs):
-    """bidiag_panel_fused (one pass over the trailing matrix per column: the row accumulators of A0 rr ride along with the
-    column dots of y) against the two-pass panel: same bidiagonal to rounding, A = Q B P^H, unitary factors."""
-    rng = np.random.default_rng(21)
-    for m in (96, 130, 203):
-        A = np.asfortranarray(rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
-        out = {}
-        for fused in (0, 1):
-            os.environ["HS_BIDIAG_FUSED"] = str(fused)
-            d, e = np.zeros(m), np.zeros(m)
-            Q, Pm = np.zeros((m, m), complex, order="F"), np.zeros((m, m), complex, order="F")
-            assert hs.hs_bidiag(A.ctypes.data_as(P), m, d.ctypes.data_as(P), e.ctypes.data_as(P), Q.ctypes.data_as(P),
-                                Pm.ctypes.data_as(P)) == 0
-            out[fused] = (d.copy(), e.copy(), Q.copy(), Pm.copy())
-        os.environ.pop("HS_BIDIAG_FUSED")
-        d0, e0, Q0, P0 = out[0]
-        d1, e1, Q1, P1 = out[1]
-        nrm = np.linalg.norm(A, 2)
-        assert np.abs(d0 - d1).max() < 1e-13 * nrm and np.abs(e0 - e1).max() < 1e-13 * nrm
-        B = np.diag(d1) + np.diag(e1[:m - 1], 1)
-        assert np.abs(Q1 @ B @ P1.conj().T - A).max() < 1e-13 * nrm
-        assert np.abs(Q1.conj().T @ Q1 - np.eye(m)).max() < 1e-13 and np.abs(P1.conj().T @ P1 - np.eye(m)).max() < 1e-13
-
-
 def _bdsdc(hs, d, e):
     m = len(d)
     hs.hs_bdsdc.argtypes = [P, P, ctypes.c_int, P, P, P]
@@ -330,7 +306,7 @@ def test_cooperative_panels_give_the_same_bits_for_every_team_size(hs, monkeypat
     """kb_team.hpp / kb_panel_team.hpp: the panels of the two blocked reductions run by teams of T "workgroups" (here T
     threads that meet in a barrier, sharing the matrices and the exchange buffer as the device's workgroups do) return the
     same BITS for every T - the split products are defined by a fixed slot decomposition, T only deals the slots - and
-    they agree with the round-3 one-workgroup panels to rounding."""
+    they are correct reductions (singular values / eigenvalues against LAPACK, reconstruction)."""
     rng = np.random.default_rng(5)
 
     def bidiag(A):
@@ -351,12 +327,7 @@ def test_cooperative_panels_give_the_same_bits_for_every_team_size(hs, monkeypat
     for m in (97, 161):                     # one and three panels of 32 columns
         A = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
         W = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
-        monkeypatch.setenv("HS_BIDIAG_FUSED", "0")
-        d0 = bidiag(A)[0]
-        monkeypatch.delenv("HS_BIDIAG_FUSED")
-        monkeypatch.setenv("HS_HESS_OLD", "1")
-        mu0 = eig(W)[0]
-        monkeypatch.delenv("HS_HESS_OLD")
+        sv0, mu0 = np.linalg.svd(A, compute_uv=False), np.linalg.eigvals(W)
         base = None
         for T in (1, 2, 3, 8):
             monkeypatch.setenv("HS_PANEL_T", str(T))
@@ -367,7 +338,8 @@ def test_cooperative_panels_give_the_same_bits_for_every_team_size(hs, monkeypat
                 base = (d, e, Q, Pm, mu, X)
                 B = np.diag(d) + np.diag(e[:m - 1], 1)
                 assert np.abs(Q @ B @ Pm.conj().T - A).max() < 1e-13 * m
-                assert np.abs(d - d0).max() < 1e-11 and np.abs(np.sort_complex(mu) - np.sort_complex(mu0)).max() < 1e-10
+                assert np.abs(np.linalg.svd(B, compute_uv=False) - sv0).max() < 1e-12 * m
+                assert np.abs(mu[:, None] - mu0[None, :]).min(axis=1).max() < 1e-10
                 assert np.abs(W @ X - X * mu).max() < 1e-12 * m
             else:
                 for a, b in zip(base, (d, e, Q, Pm, mu, X)):

@@ -11,11 +11,11 @@ from llckbdm_amd import datasets                     # noqa: E402
 from llckbdm_amd.engine import Engine                # noqa: E402
 
 
-def run(T, budget, sig, m, reps=3, old=0):
+def run(T, budget, sig, m, reps=3):
     os.environ["KBDM_PANEL_T"] = str(T)
     os.environ["KBDM_PANEL_BUDGET"] = str(budget)
-    os.environ["KBDM_PANEL_OLD"] = str(old)
     eng = Engine(0, in_flight=1)
+    eng.wide_solve = False
     idx = np.zeros(len(m), np.int32)
     res = eng.solve(sig, idx, m, dwell=5e-4)
     best = None
@@ -34,9 +34,7 @@ def run(T, budget, sig, m, reps=3, old=0):
 def main():
     Ts = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
     sig, _, m = datasets.config2()
-    ref, best = run(1, 256, sig, m, old=1)
-    print("old panels: %.2f ms  svd_fac %.2f  hess %.2f  status!=0: %d" % (best[0], best[1]["k_svd_fac"], best[1]["k_hess"],
-                                                                             int(np.count_nonzero(ref.status))), flush=True)
+    ref, best = run(1, 256, sig, m)
     base = None
     for T in Ts:
         res, best = run(T, 256, sig, m)
@@ -44,7 +42,7 @@ def main():
             base = res
         same = all(np.array_equal(getattr(res, k), getattr(base, k)) for k in ("lines", "sv", "mu", "keep", "status"))
         dev = np.abs(res.sv - ref.sv).max() / ref.sv.max()
-        print("T=%d: %.2f ms  svd_fac %.2f  hess %.2f  hqr %.2f  bitwise==T%d: %s  sv vs old panels: %.1e  status!=0: %d" %
+        print("T=%d: %.2f ms  svd_fac %.2f  hess %.2f  hqr %.2f  bitwise==T%d: %s  sv vs a team of one: %.1e  status!=0: %d" %
               (T, best[0], best[1]["k_svd_fac"], best[1]["k_hess"], best[1]["k_hqr"], Ts[0], same, dev,
                int(np.count_nonzero(res.status))), flush=True)
 

@@ -49,7 +49,6 @@ def main():
         os.environ["KBDM_LANE0_FRAC"] = p[2]
         os.environ["KBDM_LANES"] = p[3]
         os.environ["KBDM_PANEL_T_ALL"] = p[4] if len(p) > 4 else "0"
-        os.environ["KBDM_PANEL_OLD"] = p[5] if len(p) > 5 else "0"
         eng = Engine(0, in_flight=4 if fl else 1)
         ms_, st = lone(eng, sig, idx, m)
         line = "%-22s lone %.2f ms (%.0f solves/s)  svd_fac %.2f gen %.2f hess %.2f hqr %.2f invit %.2f" % (
