@@ -408,7 +408,9 @@ int panel_team_size(const kbdm_plan* pl, const Chunk& ch) {
 int panel_team_zr(int n, int nt) {
     const int fixed = KB_RED_BYTES + panel_team_scratch_bytes(n, 0, nt);
     int zr = (LDS_MAX - fixed) / (KB_TEAM_NCG * (int)sizeof(cd)) / 64 * 64;
-    return std::min(zr, (n + 63) / 64 * 64);            // (all the rows in one batch when they fit)
+    zr = std::min(zr, (n + 63) / 64 * 64);              // (all the rows in one batch when they fit)
+    static const int cap = env_int("KBDM_PANEL_ZR", 0);   // (experiments: a smaller partial-sum array leaves LDS for a second workgroup)
+    return cap >= 64 ? std::min(zr, cap / 64 * 64) : zr;
 }
 
 // Explicit unitary factors of a chunk: members with n >= KB_WY_MIN by blocked compact-WY accumulation on FP64 MFMA

@@ -140,6 +140,7 @@ typedef double kb_d4 __attribute__((ext_vector_type(4)));
 constexpr int KB_WY_MIN = 192;    // members at least this large get their unitary factors from the blocked (k_wy_*) path
 constexpr int KB_TU_KC = 8;       // k per staged chunk
 constexpr int KB_TU_PITCH = 80;   // doubles per k row in LDS
+constexpr int KB_TU_PF = 1;       // chunks of operand loads in flight ahead of the MFMAs (2 and 3 measured: 152-165 VGPRs, 1 % slower in flight)
 
 // `nch` = number of 8-deep k chunks (a runtime value: the blocked reductions use 2 NB / 8, the compact-WY generation of
 // the unitary factors uses the panel height / 8 and NB / 8); STORE = false: C -= product, true: C = product.
@@ -162,51 +163,67 @@ __device__ __forceinline__ void mfma_tile_ks2(kb_tu_stage* s_op, FA Aop, FB Bop,
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc_re[a][b] = (kb_d4){0, 0, 0, 0}; acc_im[a][b] = (kb_d4){0, 0, 0, 0}; }
-    cd ga[2], gb[2];
-    ga[0] = Aop(srowa, ska); ga[1] = Aop(srowa + srowa2, ska + ska2);
-    gb[0] = Bop(srowb, skb); gb[1] = Bop(srowb + srowb2, skb + skb2);
+    // Operand loads run KB_TU_PF chunks ahead of the MFMAs (registers: PF sets of two elements per operand and thread; a
+    // set is free again once its chunk sits in LDS).  One chunk of MFMAs lasts 0.85 us; with four ensembles in flight a
+    // load takes about 3 us, and one chunk of cover left the tile waiting for its operands 70 % of the time.
+    constexpr int PF = KB_TU_PF;
+    cd ga[PF][2], gb[PF][2];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (u < NCH) {
+            const int kna = u * KB_TU_KC + ska, knb = u * KB_TU_KC + skb;
+            ga[u][0] = Aop(srowa, kna); ga[u][1] = Aop(srowa + srowa2, kna + ska2);
+            gb[u][0] = Bop(srowb, knb); gb[u][1] = Bop(srowb + srowb2, knb + skb2);
+        }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        s_op[0][0][0][ska + ska2 * j][srowa + srowa2 * j] = ga[j].x; s_op[0][0][1][ska + ska2 * j][srowa + srowa2 * j] = ga[j].y;
-        s_op[0][1][0][skb + skb2 * j][srowb + srowb2 * j] = gb[j].x; s_op[0][1][1][skb + skb2 * j][srowb + srowb2 * j] = gb[j].y;
+        s_op[0][0][0][ska + ska2 * j][srowa + srowa2 * j] = ga[0][j].x; s_op[0][0][1][ska + ska2 * j][srowa + srowa2 * j] = ga[0][j].y;
+        s_op[0][1][0][skb + skb2 * j][srowb + srowb2 * j] = gb[0][j].x; s_op[0][1][1][skb + skb2 * j][srowb + srowb2 * j] = gb[0][j].y;
     }
     __syncthreads();
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < NCH) {
-            const int kna = (ch + 1) * KB_TU_KC + ska, knb = (ch + 1) * KB_TU_KC + skb;
-            ga[0] = Aop(srowa, kna); ga[1] = Aop(srowa + srowa2, kna + ska2);
-            gb[0] = Bop(srowb, knb); gb[1] = Bop(srowb + srowb2, knb + skb2);
-        }
+    for (int ch0 = 0; ch0 < NCH; ch0 += PF) {
 #pragma unroll
-        for (int ks = 0; ks < KB_TU_KC; ks += 4) {
-            double ar[2], ai[2], br[2], bi[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                ar[a] = s_op[buf][0][0][ks + lk][wr + a * 16 + li];
-                ai[a] = s_op[buf][0][1][ks + lk][wr + a * 16 + li];
-                br[a] = s_op[buf][1][0][ks + lk][wc + a * 16 + li];
-                bi[a] = s_op[buf][1][1][ks + lk][wc + a * 16 + li];
-            }
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    // D'[c][r] += Bop(c,k) (MFMA A operand) * Aop(r,k) (MFMA B operand), complex with conj(Bop)
-                    acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[cb], ar[rb], acc_re[cb][rb], 0, 0, 0);
-                    acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[cb], ai[rb], acc_re[cb][rb], 0, 0, 0);
-                    acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[cb], ai[rb], acc_im[cb][rb], 0, 0, 0);
-                    acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi[cb], ar[rb], acc_im[cb][rb], 0, 0, 0);
+        for (int u = 0; u < PF; ++u) {
+            const int ch = ch0 + u;
+            if (ch < NCH) {                                  // (uniform)
+                const int buf = ch & 1;
+                if (ch + PF < NCH) {                         // set u held chunk ch, staged one step ago: reuse it for chunk ch + PF
+                    const int kna = (ch + PF) * KB_TU_KC + ska, knb = (ch + PF) * KB_TU_KC + skb;
+                    ga[u][0] = Aop(srowa, kna); ga[u][1] = Aop(srowa + srowa2, kna + ska2);
+                    gb[u][0] = Bop(srowb, knb); gb[u][1] = Bop(srowb + srowb2, knb + skb2);
                 }
-        }
-        if (ch + 1 < NCH) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                s_op[buf ^ 1][0][0][ska + ska2 * j][srowa + srowa2 * j] = ga[j].x; s_op[buf ^ 1][0][1][ska + ska2 * j][srowa + srowa2 * j] = ga[j].y;
-                s_op[buf ^ 1][1][0][skb + skb2 * j][srowb + srowb2 * j] = gb[j].x; s_op[buf ^ 1][1][1][skb + skb2 * j][srowb + srowb2 * j] = gb[j].y;
+                for (int ks = 0; ks < KB_TU_KC; ks += 4) {
+                    double ar[2], ai[2], br[2], bi[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        ar[a] = s_op[buf][0][0][ks + lk][wr + a * 16 + li];
+                        ai[a] = s_op[buf][0][1][ks + lk][wr + a * 16 + li];
+                        br[a] = s_op[buf][1][0][ks + lk][wc + a * 16 + li];
+                        bi[a] = s_op[buf][1][1][ks + lk][wc + a * 16 + li];
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            // D'[c][r] += Bop(c,k) (MFMA A operand) * Aop(r,k) (MFMA B operand), complex with conj(Bop)
+                            acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[cb], ar[rb], acc_re[cb][rb], 0, 0, 0);
+                            acc_re[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[cb], ai[rb], acc_re[cb][rb], 0, 0, 0);
+                            acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[cb], ai[rb], acc_im[cb][rb], 0, 0, 0);
+                            acc_im[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi[cb], ar[rb], acc_im[cb][rb], 0, 0, 0);
+                        }
+                }
+                if (ch + 1 < NCH) {
+                    const int un = (u + 1) % PF;             // the set that holds chunk ch + 1 (a constant once the loop is unrolled)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        s_op[buf ^ 1][0][0][ska + ska2 * j][srowa + srowa2 * j] = ga[un][j].x; s_op[buf ^ 1][0][1][ska + ska2 * j][srowa + srowa2 * j] = ga[un][j].y;
+                        s_op[buf ^ 1][1][0][skb + skb2 * j][srowb + srowb2 * j] = gb[un][j].x; s_op[buf ^ 1][1][1][skb + skb2 * j][srowb + srowb2 * j] = gb[un][j].y;
+                    }
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
     // D' element (MFMA row = C column offset, MFMA col = C row offset): col = li, row = lk + 4*reg
 #pragma unroll
