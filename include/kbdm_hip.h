@@ -228,9 +228,15 @@ int kbdm_silhouette_samples(kbdm_ctx* ctx, const double* X, int n, int dim, cons
  * excess of mass, no single-cluster result; semantics of scikit-learn's HDBSCAN: the point itself counts towards
  * min_samples).  X: n x dim float64 row-major (dim <= 8); min_samples[nfits] (1 <= k <= n);
  * labels_out[nfits * n] (-1 = noise), nclusters_out[nfits] (may be null).  The O(n^2) parts (k-nearest-neighbour
- * distances once for all fits, one Prim MST per fit, all fits concurrently) run on the GPU, the trees on the host. */
+ * distances once for all fits, one Prim MST per fit, all fits concurrently) run on the GPU, the trees on the host.
+ * No limit on min_samples other than n. */
 int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* min_samples, int nfits,
                        int min_cluster_size, int32_t* labels_out, int32_t* nclusters_out);
+
+/* Core distances (the distance to the k-th nearest sample, the sample itself counted: what the sweep above feeds its
+ * mutual-reachability weights with; hdbscan's `core_distances_`) for every k of min_samples[nfits]: out[nfits * n].
+ * Same kernel, same limits as the sweep: none on k (lists that do not fit the LDS are produced in passes). */
+int kbdm_core_distances(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* min_samples, int nfits, double* out);
 
 /* The host half on its own (no GPU): labels from the n-1 edges (a[i], b[i], w[i]) of a minimum spanning tree of the
  * mutual-reachability graph.  Returns the number of clusters. */

@@ -409,8 +409,7 @@ int panel_team_zr(int n, int nt) {
     const int fixed = KB_RED_BYTES + panel_team_scratch_bytes(n, 0, nt);
     int zr = (LDS_MAX - fixed) / (KB_TEAM_NCG * (int)sizeof(cd)) / 64 * 64;
     zr = std::min(zr, (n + 63) / 64 * 64);              // (all the rows in one batch when they fit)
-    static const int cap = env_int("KBDM_PANEL_ZR", 0);   // (experiments: a smaller partial-sum array leaves LDS for a second workgroup)
-    return cap >= 64 ? std::min(zr, cap / 64 * 64) : zr;
+    return zr;
 }
 
 // Explicit unitary factors of a chunk: members with n >= KB_WY_MIN by blocked compact-WY accumulation on FP64 MFMA
@@ -1697,6 +1696,64 @@ int kbdm_hdbscan_labels_from_mst(int n, const int32_t* a, const int32_t* b, cons
     return hdbscan_labels_from_mst(n, e.data(), min_cluster_size, labels_out);
 }
 
+// The k-nearest-neighbour pass on stream st: knn[i * K + q], q < K, ascending (kbdm_next.hpp).  d_lo / d_skip: n entries each,
+// only needed (and only touched) when the lists do not fit one pass; knn_passes() tells.
+namespace {
+struct KnnGeom { int tpb, Kp, npass; };
+KnnGeom knn_geom(int K) {
+    // threads (= samples) per workgroup: as many as keep the running lists in LDS; lists longer than 8 threads' worth of
+    // LDS are produced in passes of Kp entries
+    KnnGeom g{KB_KNN_TPB, K, 1};
+    auto bytes = [&](int k, int t) { return ((size_t)k * t + (size_t)t * KB_SIL_MAXDIM) * sizeof(double); };
+    while (g.tpb > 8 && bytes(K, g.tpb) > (size_t)LDS_MAX - 64) g.tpb >>= 1;
+    if (bytes(K, g.tpb) > (size_t)LDS_MAX - 64)
+        g.Kp = (int)((((size_t)LDS_MAX - 64) / sizeof(double) - (size_t)g.tpb * KB_SIL_MAXDIM) / g.tpb);
+    g.npass = (K + g.Kp - 1) / g.Kp;
+    return g;
+}
+void launch_knn(const KnnGeom& g, hipStream_t st, const double* d_x, int n, int dim, int K, double* d_knn, double* d_lo, int* d_skip) {
+    for (int koff = 0; koff < K; koff += g.Kp) {
+        const int kp = std::min(g.Kp, K - koff);
+        const size_t lds = ((size_t)kp * g.tpb + (size_t)g.tpb * KB_SIL_MAXDIM) * sizeof(double);
+        hipLaunchKernelGGL(k_knn_dist, dim3((n + g.tpb - 1) / g.tpb), dim3(g.tpb), lds, st, d_x, n, dim, K, d_knn, koff, kp, d_lo, d_skip);
+    }
+}
+}  // namespace
+
+int kbdm_core_distances(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* min_samples, int nfits, double* out) {
+    if (!ctx || !X || !min_samples || !out || n < 2 || dim < 1 || dim > KB_SIL_MAXDIM || nfits < 1)
+        return fail(KBDM_E_INVALID, "bad core-distance arguments");
+    int K = 1;
+    for (int f = 0; f < nfits; ++f) {
+        if (min_samples[f] < 1 || min_samples[f] > n) return fail(KBDM_E_INVALID, "min_samples out of range");
+        K = std::max(K, (int)min_samples[f]);
+    }
+    const KnnGeom g = knn_geom(K);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_dist), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
+    double *d_x = nullptr, *d_knn = nullptr, *d_lo = nullptr;
+    int* d_skip = nullptr;
+    hipStream_t st = ctx->stream;
+    std::vector<double> knn((size_t)n * K);
+    int r = KBDM_OK;
+    do {
+        if (hipMalloc(&d_x, sizeof(double) * n * dim) != hipSuccess || hipMalloc(&d_knn, sizeof(double) * (size_t)n * K) != hipSuccess ||
+            (g.npass > 1 && (hipMalloc(&d_lo, sizeof(double) * n) != hipSuccess || hipMalloc(&d_skip, sizeof(int) * n) != hipSuccess))) {
+            r = fail(KBDM_E_NOMEM, "hipMalloc (core distances)");
+            break;
+        }
+        hipMemcpyAsync(d_x, X, sizeof(double) * n * dim, hipMemcpyHostToDevice, st);
+        launch_knn(g, st, d_x, n, dim, K, d_knn, d_lo, d_skip);
+        hipMemcpyAsync(knn.data(), d_knn, sizeof(double) * knn.size(), hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "k-nearest-neighbour kernel failed"); break; }
+    } while (0);
+    hipFree(d_x); hipFree(d_knn); hipFree(d_lo); hipFree(d_skip);
+    if (r) return r;
+    for (int f = 0; f < nfits; ++f)
+        for (int i = 0; i < n; ++i) out[(size_t)f * n + i] = knn[(size_t)i * K + min_samples[f] - 1];
+    return KBDM_OK;
+}
+
 int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* min_samples, int nfits,
                        int min_cluster_size, int32_t* labels_out, int32_t* nclusters_out) {
     if (!ctx || !X || !min_samples || !labels_out || n < 2 || dim < 1 || dim > KB_SIL_MAXDIM || nfits < 1 || min_cluster_size < 2)
@@ -1706,16 +1763,12 @@ int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int
         if (min_samples[f] < 1 || min_samples[f] > n) return fail(KBDM_E_INVALID, "min_samples out of range");
         K = std::max(K, (int)min_samples[f]);
     }
-    // threads (= samples) per workgroup of the k-nearest-neighbour pass: as many as keep K running lists in LDS
-    int tpb = KB_KNN_TPB;
-    auto knn_lds = [&](int t) { return ((size_t)K * t + (size_t)t * KB_SIL_MAXDIM) * sizeof(double); };
-    while (tpb > 8 && knn_lds(tpb) > (size_t)LDS_MAX - 64) tpb >>= 1;
-    const size_t lds = knn_lds(tpb);
-    if (lds > (size_t)LDS_MAX - 64) return fail(KBDM_E_NOMEM, "min_samples too large for the k-nearest-neighbour kernel");
+    const KnnGeom g = knn_geom(K);
+    const int npass = g.npass;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_dist), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 64));
-    double *d_x = nullptr, *d_knn = nullptr, *d_best = nullptr, *d_core = nullptr;
-    int *d_ms = nullptr, *d_src = nullptr;
+    double *d_x = nullptr, *d_knn = nullptr, *d_best = nullptr, *d_core = nullptr, *d_lo = nullptr;
+    int *d_ms = nullptr, *d_src = nullptr, *d_skip = nullptr;
     KbEdge* d_edges = nullptr;
     hipStream_t st = ctx->stream;
     std::vector<KbEdge> edges((size_t)nfits * (n - 1));
@@ -1724,18 +1777,19 @@ int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int
         if (hipMalloc(&d_x, sizeof(double) * n * dim) != hipSuccess || hipMalloc(&d_knn, sizeof(double) * (size_t)n * K) != hipSuccess ||
             hipMalloc(&d_best, sizeof(double) * (size_t)n * nfits) != hipSuccess || hipMalloc(&d_core, sizeof(double) * (size_t)n * nfits) != hipSuccess ||
             hipMalloc(&d_src, sizeof(int) * (size_t)n * nfits) != hipSuccess ||
-            hipMalloc(&d_ms, sizeof(int) * nfits) != hipSuccess || hipMalloc(&d_edges, sizeof(KbEdge) * (size_t)nfits * (n - 1)) != hipSuccess) {
+            hipMalloc(&d_ms, sizeof(int) * nfits) != hipSuccess || hipMalloc(&d_edges, sizeof(KbEdge) * (size_t)nfits * (n - 1)) != hipSuccess ||
+            (npass > 1 && (hipMalloc(&d_lo, sizeof(double) * n) != hipSuccess || hipMalloc(&d_skip, sizeof(int) * n) != hipSuccess))) {
             r = fail(KBDM_E_NOMEM, "hipMalloc (hdbscan)");
             break;
         }
         hipMemcpyAsync(d_x, X, sizeof(double) * n * dim, hipMemcpyHostToDevice, st);
         hipMemcpyAsync(d_ms, min_samples, sizeof(int) * nfits, hipMemcpyHostToDevice, st);
-        hipLaunchKernelGGL(k_knn_dist, dim3((n + tpb - 1) / tpb), dim3(tpb), lds, st, d_x, n, dim, K, d_knn);
+        launch_knn(g, st, d_x, n, dim, K, d_knn, d_lo, d_skip);
         hipLaunchKernelGGL(k_prim_mst, dim3(nfits), dim3(1024), 0, st, d_x, n, dim, K, d_knn, d_ms, d_best, d_core, d_src, d_edges);
         hipMemcpyAsync(edges.data(), d_edges, sizeof(KbEdge) * edges.size(), hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "hdbscan kernels failed"); break; }
     } while (0);
-    hipFree(d_x); hipFree(d_knn); hipFree(d_best); hipFree(d_core); hipFree(d_src); hipFree(d_ms); hipFree(d_edges);
+    hipFree(d_x); hipFree(d_knn); hipFree(d_best); hipFree(d_core); hipFree(d_src); hipFree(d_ms); hipFree(d_edges); hipFree(d_lo); hipFree(d_skip);
     if (r) return r;
     // the trees: independent per fit, a few host threads
     const int nthreads = std::max(1, std::min(nfits, std::min(16, (int)std::thread::hardware_concurrency())));

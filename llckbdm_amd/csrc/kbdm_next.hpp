@@ -118,18 +118,23 @@ namespace kb {
 // HDBSCAN sweep, the O(n^2) parts (the tree part is host code: kbdm_cluster.hpp).
 //
 // k_knn_dist: for every sample the K smallest distances to the samples (itself included, so entry 0 is 0),
-// ascending: knn[i * K + q].  One thread per sample; the running top-K of a thread lives in LDS laid out
+// ascending: knn[i * K + q].  One thread per sample; the running list of a thread lives in LDS laid out
 // [q][thread] (conflict-free); candidates stream through registers from an LDS tile; a candidate is inserted only
-// if it beats the current K-th best (after the first few tiles that is rare).  The workgroup size is chosen by the
-// host so that K lists fit the LDS: 64 threads up to K = 300, then 32 / 16 / 8 (K up to ~2300: every min_samples of
-// a 1001-member m_range stays on the GPU).
+// if it beats the current last entry of the list (after the first few tiles that is rare).  The workgroup size is
+// chosen by the host so that the lists fit the LDS: 64 threads up to K = 300, then 32 / 16 / 8 (K up to ~2300).
+// Beyond that the host runs the kernel in PASSES of Kp entries: pass p writes entries koff .. koff + Kp - 1, the
+// Kp smallest candidates that come AFTER everything earlier passes wrote, in the order (distance, sample index).
+// A pass only needs two numbers per sample from the passes before it: the last distance written (lo) and how many
+// candidates of exactly that distance are already out (skipc) - candidates arrive in index order and equal ones keep
+// that order in the list, so "skip the first skipc candidates equal to lo" is the continuation.  No limit on K.
 #define KB_KNN_TPB 64
 __global__ void __launch_bounds__(KB_KNN_TPB) k_knn_dist(const double* __restrict__ xs, int n, int dim, int K,
-                                                          double* __restrict__ knn) {
+                                                          double* __restrict__ knn, int koff, int Kp,
+                                                          double* __restrict__ lo, int* __restrict__ skipc) {
     extern __shared__ double kb_knn_lds[];
     const int tpb = blockDim.x;
-    double* top = kb_knn_lds;                                  // K x tpb
-    double* tile = kb_knn_lds + (size_t)K * tpb;               // tpb x MAXDIM
+    double* top = kb_knn_lds;                                  // Kp x tpb
+    double* tile = kb_knn_lds + (size_t)Kp * tpb;              // tpb x MAXDIM
     const int t = threadIdx.x;
     const int i = blockIdx.x * tpb + t;
     const bool live = i < n;
@@ -137,8 +142,11 @@ __global__ void __launch_bounds__(KB_KNN_TPB) k_knn_dist(const double* __restric
 #pragma unroll
     for (int d = 0; d < KB_SIL_MAXDIM; ++d) xi[d] = (live && d < dim) ? xs[(size_t)i * dim + d] : 0.0;
     const double inf = 1.79769313486231570815e308;
-    for (int q = 0; q < K; ++q) top[q * tpb + t] = inf;
-    double kth = inf;                                          // current K-th best of this thread
+    for (int q = 0; q < Kp; ++q) top[q * tpb + t] = inf;
+    double kth = inf;                                          // current last entry of this thread's list
+    const double lo_d = (koff > 0 && live) ? lo[i] : -1.0;     // distances are >= 0: -1 excludes nothing
+    const int skip0 = (koff > 0 && live) ? skipc[i] : 0;
+    int skip = skip0;
     for (int jb = 0; jb < n; jb += tpb) {
         const int cnt = (n - jb < tpb) ? n - jb : tpb;
         __syncthreads();
@@ -151,18 +159,27 @@ __global__ void __launch_bounds__(KB_KNN_TPB) k_knn_dist(const double* __restric
                 for (int d = 0; d < KB_SIL_MAXDIM; ++d)
                     if (d < dim) { const double df = xi[d] - tile[j * dim + d]; d2 = fma(df, df, d2); }
                 const double dj = sqrt(d2);
-                if (dj < kth) {
-                    // insert into the ascending list (shift the tail down by one)
-                    int q = K - 1;
+                if (dj < kth && dj >= lo_d) {
+                    if (dj == lo_d && skip > 0) { --skip; continue; }          // written by an earlier pass
+                    // insert into the ascending list (shift the tail down by one; equal entries keep arrival order)
+                    int q = Kp - 1;
                     while (q > 0 && top[(q - 1) * tpb + t] > dj) { top[q * tpb + t] = top[(q - 1) * tpb + t]; --q; }
                     top[q * tpb + t] = dj;
-                    kth = top[(K - 1) * tpb + t];
+                    kth = top[(Kp - 1) * tpb + t];
                 }
             }
         }
     }
-    if (live)
-        for (int q = 0; q < K; ++q) knn[(size_t)i * K + q] = top[q * tpb + t];
+    if (live) {
+        for (int q = 0; q < Kp; ++q) knn[(size_t)i * K + koff + q] = top[q * tpb + t];
+        if (lo) {
+            const double last = top[(Kp - 1) * tpb + t];
+            int c = 0;
+            for (int q = Kp - 1; q >= 0 && top[q * tpb + t] == last; --q) ++c;
+            lo[i] = last;
+            skipc[i] = (last == lo_d ? skip0 : 0) + c;
+        }
+    }
 }
 
 // k_prim_mst: one workgroup per fit (value of min_samples): Prim's algorithm from sample 0 over the complete graph

@@ -544,6 +544,15 @@ class Engine:
                                                int(min_cluster_size), _lib.ptr(labels), _lib.ptr(ncl)))
         return labels, ncl
 
+    def core_distances(self, X, min_samples_list):
+        """Distance of every sample to its k-th nearest sample (itself counted) for every k of the list: [nfits, n].
+        The k-nearest-neighbour pass of `hdbscan_sweep` on its own."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        ms = np.ascontiguousarray(min_samples_list, dtype=np.int32)
+        out = np.empty((len(ms), X.shape[0]), dtype=np.float64)
+        _lib.check(self.lib.kbdm_core_distances(self.ctx, _lib.ptr(X), X.shape[0], X.shape[1], _lib.ptr(ms), len(ms), _lib.ptr(out)))
+        return out
+
     def eig(self, mats):
         n = np.array([a.shape[0] for a in mats], dtype=np.int32)
         flat = np.concatenate([np.ascontiguousarray(a, dtype=np.complex128).ravel() for a in mats])

@@ -49,8 +49,6 @@ class ClusteringResult:
 
 
 MIN_CLUSTER_SIZE = 5        # hdbscan.HDBSCAN's default, which the reference does not change (llckbdm.py:280)
-GPU_SWEEP_MAX_K = 2300      # the k-nearest-neighbour pass of `Engine.hdbscan_sweep` keeps a thread's K candidates in LDS and
-                            # shrinks its workgroups from 64 to 8 threads as K grows; 8 K + 64 doubles must fit 160 KB
 
 
 def _fit_labels(transformed_samples, min_samples, clusterer, engine):
@@ -88,12 +86,7 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None, clusterer="g
     if clusterer == "gpu" and len(transformed_line_list) >= 2:
         fits = [k for k in sweep if k <= len(transformed_line_list)]
         labels_all = {}
-        if fits and max(fits) > GPU_SWEEP_MAX_K:
-            # no silent host path: the product computes on the GPU or says why it cannot
-            raise ValueError(f"llc_kbdm: an m_range of {m_range_size} members sweeps min_samples up to {max(fits)}; the GPU "
-                             f"clusterer holds a sample's nearest-neighbour list in LDS and stops at {GPU_SWEEP_MAX_K}. "
-                             "Pass clusterer='sklearn' (host, scikit-learn) explicitly, or shorten m_range.")
-        if fits:
+        if fits:                     # every fit on the GPU, whatever min_samples (no host clusterer behind the caller's back)
             got, _ = eng.hdbscan_sweep(transformed_line_list, fits, MIN_CLUSTER_SIZE)
             labels_all.update(zip(fits, got))
     for min_samples in sweep:

@@ -136,3 +136,45 @@ def test_sweep_degenerate_inputs(eng):
         eng.hdbscan_sweep(X, [0])
     with pytest.raises(Exception):
         eng.hdbscan_sweep(X, [41])
+
+
+def test_core_distances_in_passes_bit_exact_on_a_lattice_full_of_ties(eng):
+    """min_samples beyond one LDS list (about 2550 at 8 samples per workgroup): the k-nearest-neighbour kernel runs in
+    passes that continue each other in (distance, index) order.  Integer lattice points with duplicates: every squared
+    distance is a small integer, so sqrt is exact on both sides and whole runs of equal distances straddle the pass
+    boundaries.  Bit-exact against a full numpy sort, for one, two and three passes."""
+    rng = np.random.default_rng(12)
+    X = rng.integers(0, 7, (5300, 4)).astype(np.float64)
+    D = np.sqrt(((X[:, None, :] - X[None, :, :]) ** 2).sum(-1))
+    D.sort(axis=1)
+    ks = [1, 2, 300, 2551, 2552, 2600, 5102, 5103, 5299, 5300]
+    got = eng.core_distances(X, ks)
+    for f, k in enumerate(ks):
+        assert np.array_equal(got[f], D[:, k - 1]), k
+    sub = eng.core_distances(X[:2700], [2650, 2700])                    # two passes, the last one short
+    D2 = np.sort(np.sqrt(((X[:2700, None, :] - X[None, :2700, :]) ** 2).sum(-1)), axis=1)
+    assert np.array_equal(sub[0], D2[:, 2649]) and np.array_equal(sub[1], D2[:, 2699])
+
+
+def test_core_distances_random_points_and_sweep_beyond_one_pass(eng):
+    """Random points (no ties): the passes against numpy to rounding (numpy sums squares without fma), and the sweep
+    itself with min_samples beyond one pass against the documented Prim rule."""
+    from llckbdm_amd import _lib
+    rng = np.random.default_rng(13)
+    X = _data(rng, 2500, 3, 0.4, 200)
+    D = np.sqrt(((X[:, None, :] - X[None, :, :]) ** 2).sum(-1))
+    Ds = np.sort(D, axis=1)
+    ks = [2560, 2690]
+    got = eng.core_distances(X, ks)
+    for f, k in enumerate(ks):
+        np.testing.assert_allclose(got[f], Ds[:, k - 1], rtol=1e-14, atol=1e-14)
+    labels, _ = eng.hdbscan_sweep(X, ks)
+    lib = _lib.load()
+    for f, k in enumerate(ks):
+        e = _prim_reference(X, k)
+        a = np.array([x[0] for x in e], dtype=np.int32)
+        b = np.array([x[1] for x in e], dtype=np.int32)
+        w = np.array([x[2] for x in e], dtype=np.float64)
+        ref = np.empty(len(X), dtype=np.int32)
+        lib.kbdm_hdbscan_labels_from_mst(len(X), _lib.ptr(a), _lib.ptr(b), _lib.ptr(w), 5, _lib.ptr(ref))
+        assert np.array_equal(labels[f], ref), k

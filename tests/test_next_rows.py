@@ -107,22 +107,24 @@ def test_llc_kbdm_host_logic(gnext):
 
 
 def test_llc_kbdm_has_no_silent_host_clusterer(gnext, monkeypatch):
-    """a sweep whose min_samples exceed what the GPU clusterer holds raises (naming the explicit opt-in)
-    instead of handing those fits to scikit-learn on the host behind the caller's back."""
+    """with clusterer='gpu' EVERY fit of the sweep goes to the engine (the k-nearest-neighbour kernel has no
+    limit on min_samples since round 4): one batched call, no per-fit host path."""
     import llckbdm_amd.llckbdm as M
+    seen = []
 
     class Eng(OracleEngine):
         def hdbscan_sweep(self, X, ks, mcs=5):
-            assert max(ks) <= M.GPU_SWEEP_MAX_K
+            seen.append(list(ks))
             return super().hdbscan_sweep(X, ks, mcs)
     sig = gnext["sig2048"][:512]                       # (control flow only: small members keep the oracle cheap)
-    monkeypatch.setattr(M, "GPU_SWEEP_MAX_K", 3)
-    with pytest.raises(ValueError, match="clusterer='sklearn'"):
-        M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(60, 66), p=1, l=24, engine=Eng())
-    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(60, 64), p=1, l=24, engine=Eng())       # sweep 1..3: on the "GPU"
+
+    def never(*a, **k):
+        raise AssertionError("a per-fit host clusterer ran although clusterer='gpu'")
+    monkeypatch.setattr(M, "_fit_labels", never)
+    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(60, 66), p=1, l=24, engine=Eng())
     assert len(res.line_list) > 0
-    res = M.llc_kbdm(data=sig, dwell=DWELL, m_range=range(60, 66), p=1, l=24, engine=Eng(), clusterer="sklearn")
-    assert len(res.line_list) > 0
+    assert seen == [[1, 2, 3, 4, 5]]                   # the whole sweep (llckbdm.py:104), one batched call
+    assert not hasattr(M, "GPU_SWEEP_MAX_K")
 
 
 def test_hdbscan_tree_part_against_sklearn():
