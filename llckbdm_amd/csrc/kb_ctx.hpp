@@ -125,6 +125,20 @@ struct DevCtx {
         __syncthreads();
         return t;
     }
+    // block_sum_l in two halves with the caller's barrier (sync_lds) between them: work that only needs the barrier, not the
+    // sum, goes in front of it.  The slots are free again after the NEXT barrier behind red_get.
+    __device__ __forceinline__ void red_put(double v) const {
+        double* red = reinterpret_cast<double*>(smem);
+        v = wave_sum(v);
+        if (lane() == 0) red[wave()] = v;
+    }
+    __device__ __forceinline__ double red_get() const {
+        const double* red = reinterpret_cast<const double*>(smem);
+        double t = 0.0;
+        const int nw = nwaves();
+        for (int w = 0; w < nw; ++w) t += red[w];
+        return t;
+    }
     // the same with LDS-only barriers (sync_lds)
     __device__ __forceinline__ double block_sum_l(double v) const {
         double* red = reinterpret_cast<double*>(smem);
@@ -202,6 +216,8 @@ struct HostCtx {
     cd oct_sum(cd v) const { return v; }
     double block_sum_l(double v) const { return v; }
     double block_max_l(double v) const { return v; }
+    void red_put(double v) const { *reinterpret_cast<double*>(smem) = v; }
+    double red_get() const { return *reinterpret_cast<const double*>(smem); }
     void wave_fence() const {}
     void lds_fence() const {}
     void lds_order() const {}

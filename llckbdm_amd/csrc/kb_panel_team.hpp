@@ -214,31 +214,42 @@ KB_HD bool bidiag_panel_team(const C& ctx, PanelTeam<C>& tm, int n, cd* A, int l
         // a synchronisation yet); KB_NB <= the workgroup size on the device, the host loops
         cd pra = czero(), prb = czero();
         if (C::WS > 1 && tid < j) { pra = A_(j, tid); prb = (tid == j - 1) ? xl[j] : X_(j, tid); }
-        larfg<C, true>(ctx, n - j, vc + j, beta, tq);
-        ctx.sync_lds();
+        // w1 = V^H v, w2 = X^H v (replicated): v = [1; s x] with the generator's scale s, so the dots with the RAW tail x run
+        // in front of the generator's barrier (larfg_front) and w = conj(row j) + s (tail^H x) follows without another pass
+        const cd sl = larfg_front(ctx, n - j, vc + j, beta, tq, [&]() {
+            for (int t = ctx.wave(); t < 2 * j; t += nw) {
+                const bool second = t >= j;
+                const int tt = second ? t - j : t;
+                cd acc;
+                if (second && tt == j - 1) acc = team_dotc4(ctx, j + 1, n, [&](int r) { return xl[r]; }, vc);
+                else {
+                    const cd* __restrict__ src = second ? &X_(0, tt) : &A_(0, tt);
+                    acc = team_dotc4(ctx, j + 1, n, [&](int r) { return src[r]; }, vc);
+                }
+                acc = ctx.wave_sum(acc);
+                if (lane == 0) { if (second) w2[tt] = acc; else w1[tt] = acc; }
+            }
+        });
         if (tid == 0) {
             vc[j] = mk(1.0, 0.0);
             if (writer) { d[j] = beta; tauq[j] = tq; }
         }
-        for (int r = j + 1 + tid; r < n; r += nt) A_(r, j) = vc[r];
-        if (C::WS > 1) { if (tid < j) { ra[tid] = pra; rb[tid] = prb; } }
-        else for (int t = tid; t < j; t += nt) { ra[t] = A_(j, t); rb[t] = (t == j - 1) ? xl[j] : X_(j, t); }
+        for (int r = j + 1 + tid; r < n; r += nt) A_(r, j) = vc[r];             // (the entries this thread has just scaled)
+        if (C::WS > 1) {
+            if (tid < j) {
+                ra[tid] = pra; rb[tid] = prb;
+                w1[tid] = conj(pra) + w1[tid] * sl;
+                w2[tid] = conj(prb) + w2[tid] * sl;
+            }
+        } else
+            for (int t = tid; t < j; t += nt) {
+                ra[t] = A_(j, t); rb[t] = (t == j - 1) ? xl[j] : X_(j, t);
+                w1[t] = conj(ra[t]) + w1[t] * sl;
+                w2[t] = conj(rb[t]) + w2[t] * sl;
+            }
         ctx.sync_lds();
         KB_PROF(1);
-        // ---- w1 = V^H v, w2 = X^H v (replicated) and the column dots A0^H v of the owned blocks of 32 columns
-        for (int t = ctx.wave(); t < 2 * j; t += nw) {
-            const bool second = t >= j;
-            const int tt = second ? t - j : t;
-            cd acc;
-            if (second && tt == j - 1) acc = team_dotc4(ctx, j, n, [&](int r) { return xl[r]; }, vc);
-            else {
-                const cd* __restrict__ src = second ? &X_(0, tt) : &A_(0, tt);
-                acc = team_dotc4(ctx, j, n, [&](int r) { return src[r]; }, vc);
-            }
-            acc = ctx.wave_sum(acc);
-            if (lane == 0) { if (second) w2[tt] = acc; else w1[tt] = acc; }
-        }
-        KB_PROF_SYNC(2);
+        KB_PROF(2);
         const int nr = n - j - 1;
         const int nblk = (nr + KB_TEAM_CB - 1) / KB_TEAM_CB;
         const int nownb = team_own_count(nblk, role, T);
@@ -296,36 +307,44 @@ KB_HD bool bidiag_panel_team(const C& ctx, PanelTeam<C>& tm, int n, cd* A, int l
         double be;
         cd tp;
         const bool nextcol = j + 1 < KB_NB;
-        // rows j+1 of Y and of U for the sweep below, fetched under the generator (Y(:, j) from LDS)
-        if (C::WS > 1 && nextcol && tid <= j) { pra = (tid == j) ? yr[j + 1] : Y_(j + 1, tid); prb = (tid < j) ? U_(j + 1, tid) : czero(); }
-        larfg<C, true>(ctx, nr, ub, be, tp);
-        ctx.sync_lds();
+        // rows j+1 of Y and of U (for the dots below and for the sweep), fetched under the generator (Y(:, j) from LDS)
+        if (C::WS > 1 && tid <= j) { pra = (tid == j) ? yr[j + 1] : Y_(j + 1, tid); prb = (tid < j) ? U_(j + 1, tid) : czero(); }
+        // ---- x_j = taup (A^(j) u - v (y^H u)), rows j+1..n-1: z1 = Y^H u (t <= j), z2 = U^H u (t < j) replicated, from the
+        // raw row in front of the generator's barrier as on the left ...
+        const cd su = larfg_front(ctx, nr, ub, be, tp, [&]() {
+            const cd* ubc = ub - (j + 1);                          // ubc[c] = u_j(c)
+            for (int t = ctx.wave(); t < 2 * j + 1; t += nw) {
+                const bool second = t > j;
+                const int tt = second ? t - j - 1 : t;
+                cd acc;
+                if (!second && tt == j) acc = team_dotc4(ctx, j + 2, n, [&](int c) { return yr[c]; }, ubc);
+                else {
+                    const cd* __restrict__ src = second ? &U_(0, tt) : &Y_(0, tt);
+                    acc = team_dotc4(ctx, j + 2, n, [&](int c) { return src[c]; }, ubc);
+                }
+                acc = ctx.wave_sum(acc);
+                if (lane == 0) { if (second) z2[tt] = acc; else z1[tt] = acc; }
+            }
+        });
         if (tid == 0) {
             ub[0] = mk(1.0, 0.0);
             if (writer) { e[j] = be; taup[j] = tp; }
         }
-        if (nextcol) {
-            if (C::WS > 1) { if (tid <= j) { ra[tid] = pra; rb[tid] = prb; } }
-            else for (int t = tid; t <= j; t += nt) { ra[t] = (t == j) ? yr[j + 1] : Y_(j + 1, t); rb[t] = (t < j) ? U_(j + 1, t) : czero(); }
-        }
+        if (C::WS > 1) {
+            if (tid <= j) {
+                ra[tid] = pra; rb[tid] = prb;
+                z1[tid] = conj(pra) + z1[tid] * su;
+                if (tid < j) z2[tid] = conj(prb) + z2[tid] * su;
+            }
+        } else
+            for (int t = tid; t <= j; t += nt) {
+                ra[t] = (t == j) ? yr[j + 1] : Y_(j + 1, t); rb[t] = (t < j) ? U_(j + 1, t) : czero();
+                z1[t] = conj(ra[t]) + z1[t] * su;
+                if (t < j) z2[t] = conj(rb[t]) + z2[t] * su;
+            }
         ctx.sync_lds();
         for (int c = j + 1 + tid; c < n; c += nt) U_(c, j) = ub[c - j - 1];     // explicit 1 at row j+1
         KB_PROF(7);
-        // ---- x_j = taup (A^(j) u - v (y^H u)), rows j+1..n-1: z1 = Y^H u (t <= j), z2 = U^H u (t < j) replicated ...
-        for (int t = ctx.wave(); t < 2 * j + 1; t += nw) {
-            const bool second = t > j;
-            const int tt = second ? t - j - 1 : t;
-            cd acc;
-            const cd* ubc = ub - (j + 1);                          // ubc[c] = u_j(c)
-            if (!second && tt == j) acc = team_dotc4(ctx, j + 1, n, [&](int c) { return yr[c]; }, ubc);
-            else {
-                const cd* __restrict__ src = second ? &U_(0, tt) : &Y_(0, tt);
-                acc = team_dotc4(ctx, j + 1, n, [&](int c) { return src[c]; }, ubc);
-            }
-            acc = ctx.wave_sum(acc);
-            if (lane == 0) { if (second) z2[tt] = acc; else z1[tt] = acc; }
-        }
-        ctx.sync_lds();
         KB_PROF(8);
         // ---- ... the corrections of x_j with the panel factors and column j + 1 of A^(j+1), for the owned rows
         const int nrc = (nr + C::WS - 1) / C::WS;
@@ -479,25 +498,24 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
         cd tau;
         const bool nextcol = j + 1 < KB_NB;
         cd pra = czero();                                          // row k+1 of V (columns t < j), fetched under the generator
-        if (C::WS > 1 && nextcol && tid < j) pra = hess_vt(W, ld, p0, k + 1, tid);
-        larfg<C, true>(ctx, N - k - 1, xc + k + 1, beta, tau);
-        ctx.sync_lds();
-        for (int r = tid; r < N; r += nt) W_(r, k) = (r == k + 1) ? mk(beta, 0.0) : xc[r];
+        if (C::WS > 1 && tid < j) pra = hess_vt(W, ld, p0, k + 1, tid);
+        // w1 = V_j^H v (replicated): v = [1; s x], the dots with the raw tail in front of the generator's barrier (larfg_front)
+        const cd sh = larfg_front(ctx, N - k - 1, xc + k + 1, beta, tau, [&]() {
+            for (int t = ctx.wave(); t < j; t += nw) {
+                cd acc = team_dotc4(ctx, k + 2, N, [&](int r) { return hess_vt(W, ld, p0, r, t); }, xc);
+                acc = ctx.wave_sum(acc);
+                if (lane == 0) w1[t] = acc;
+            }
+        });
+        for (int r = tid; r <= k; r += nt) W_(r, k) = xc[r];
+        for (int r = k + 2 + tid; r < N; r += nt) W_(r, k) = xc[r];                 // (the entries this thread has just scaled)
         if (tid == 0) {
+            W_(k + 1, k) = mk(beta, 0.0);
             xc[k + 1] = mk(1.0, 0.0);
             if (writer) tauh[j] = tau;
         }
-        if (nextcol) {
-            if (C::WS > 1) { if (tid < j) ra[tid] = pra; }
-            else for (int t = tid; t < j; t += nt) ra[t] = hess_vt(W, ld, p0, k + 1, t);
-        }
-        ctx.sync_lds();
-        // ---- w1 = V_j^H v (replicated)
-        for (int t = ctx.wave(); t < j; t += nw) {
-            cd acc = team_dotc4(ctx, k + 1, N, [&](int r) { return hess_vt(W, ld, p0, r, t); }, xc);
-            acc = ctx.wave_sum(acc);
-            if (lane == 0) w1[t] = acc;
-        }
+        if (C::WS > 1) { if (tid < j) { ra[tid] = pra; w1[tid] = conj(pra) + w1[tid] * sh; } }
+        else for (int t = tid; t < j; t += nt) { ra[t] = hess_vt(W, ld, p0, k + 1, t); w1[t] = conj(ra[t]) + w1[t] * sh; }
         ctx.sync_lds();
         // ---- the corrections Y_j w1 of y and of the next column, for the owned rows (Y(:, j-1) from LDS)
         team_sweep8(ctx, nownc * C::WS,
