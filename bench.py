@@ -287,10 +287,10 @@ def build_rooflines(ms, n0, stage_ms, kernel_ms):
         for k, v in stage_flops(m, m).items():
             fl[k] = fl.get(k, 0.0) + v
     npan = lambda m: (m - 64) // 32 if m >= 96 else 0
-    # the one-stage panels stream the trailing matrix twice (bidiagonalisation) / once (Hessenberg: all rows x the trailing
+    # the one-stage panels stream the trailing matrix twice (bidiagonalisation) / once (Hessenberg: the rows below the panel's first x the trailing
     # columns) per column: the bytes of the ALGORITHM, not compulsory traffic
     b_bidiag = sum(sum(2 * 16.0 * (m - c) ** 2 for c in range(npan(m) * 32)) for m in lane0)
-    b_hess = sum(sum(16.0 * m * (m - c - 1) for c in range(npan(m) * 32)) for m in lane0)
+    b_hess = sum(sum(16.0 * (m - (c // 32) * 32 - 1) * (m - c - 1) for c in range(npan(m) * 32)) for m in lane0)
     b_hankel = sum(16.0 * m * m + 16.0 * (2 * m - 1) for m in lane0)
     # flops of the blocked reductions inside their panel columns: half in the panel's matrix-vector products, half in the update
     f_trail = sum(sum(8.0 * 64 * (m - 32 * (p + 1)) ** 2 for p in range(npan(m))) for m in lane0)     # rank-64 complex updates
@@ -298,7 +298,7 @@ def build_rooflines(ms, n0, stage_ms, kernel_ms):
     spec = {   # kernel: (bound, algorithmic quantity over all launches of the stage, unit, note)
         "k_ab_iter": ("mfma", fl["k_hqr"], "flop", "eigenvalue stage (Ehrlich-Aberth): 65.33 l^3 per member (SURVEY 8d)"),
         "k_bidiag_panel_team": ("hbm", b_bidiag, "B", "two passes over the trailing matrix per panel column, 32 (n - j)^2 B"),
-        "k_hess_panel_team": ("hbm", b_hess, "B", "one pass over all rows x the trailing columns per panel column, 16 n (n - k - 1) B"),
+        "k_hess_panel_team": ("hbm", b_hess, "B", "one pass over the rows below the panel's first row x the trailing columns per panel column, 16 (n - p0 - 1)(n - k - 1) B"),
         "k_trail_update": ("mfma", f_trail, "flop", "rank-64 trailing update: the zgemm half of the blocked bidiagonalisation (north_star's SVD panel update)"),
         "k_hess_update": ("mfma", f_hupd, "flop", "rank-64 update of the Hessenberg reduction"),
         "k_hankel": ("hbm", b_hankel, "B", "16 m^2 B written + the signal segment read per member (pipeline: U^{p-1} only)"),

@@ -57,8 +57,8 @@ KB_HD void gehd2(const C& ctx, int n, cd* W, int ld, cd* tauh, int k0 = 0) {
 //   y_j = tau_j (A0 v_j - Y_j (V_j^H v_j)) ,   T(0:j, j) = -tau_j T_j (V_j^H v_j) ,  T(j, j) = tau_j ,
 // so inside a panel of KB_NB columns only the current column is formed explicitly,
 //   x = A0(:, k) - Y_j V_j(k, :)^H ,   column k of A^(j) = x - V_j T_j^H (V_j^H x) ,
-// and the untouched A0 is streamed ONCE per column (the product A0 v_j; the left factors never need a pass of
-// their own inside the panel).  All columns to the right of the panel then receive ONE rank-2NB update
+// and the untouched A0 is streamed ONCE per column (the product A0 v_j, rows below the panel's first row only: the
+// rows above follow after the panel, hess_ytop_block; the left factors never need a pass of their own inside the panel).  All columns to the right of the panel then receive ONE rank-2NB update
 //   A <- A0 - Y V^H - V Z^H ,   Z = (A0^H V - V (Y^H V)) T = A0^H (V T) - V (Y^H V T)
 // (k_hess_z: one more pass over the trailing columns for all NB vectors at once, then k_hess_update on FP64
 // MFMA).  The panel leaves VT = V T (N x NB) and MT = (Y^H V) T (NB x NB) for k_hess_z.
@@ -82,6 +82,29 @@ KB_HD void hess_z_block(const C& ctx, int N, const cd* W, int ld, int p0, const 
         for (int r = p0 + 1; r < N; ++r) cfmac(acc, W[r + (size_t)c * ld], VT[r + (size_t)t * ldvt]);
         for (int u = 0; u < KB_NB; ++u) acc = acc - hess_vt(W, ld, p0, c, u) * MT[u + t * KB_NB];
         Z[c + (size_t)t * ldz] = acc;
+    }
+    ctx.sync();
+}
+
+// The rows above a panel (r <= p0), which hess_panel_team leaves alone: their share of Y = A0 V T and their entries in the
+// panel's own columns,
+//   Y(r, t) = sum_{c > p0} A0(r, c) VT(c, t) ,      W(r, p0 + j) -= sum_{t < j} Y(r, t) conj(V(p0 + j, t)) ,  j = 1 .. NB - 1
+// (zlahr2 finishes a panel the same way).  Reference form; the device kernel k_hess_ytop computes the first sum as FP64-MFMA
+// tiles.  The columns right of the panel receive Y(r, :) with everybody else's rows in the rank-2NB update.
+template <class C>
+KB_HD void hess_ytop_block(const C& ctx, int N, cd* W, int ld, int p0, const cd* VT, int ldvt, cd* Y, int ldy) {
+    for (int idx = ctx.tid(); idx < (p0 + 1) * KB_NB; idx += ctx.nthreads()) {
+        const int r = idx % (p0 + 1), t = idx / (p0 + 1);
+        cd acc = czero();
+        for (int c = p0 + 1; c < N; ++c) cfma(acc, W[r + (size_t)c * ld], VT[c + (size_t)t * ldvt]);
+        Y[r + (size_t)t * ldy] = acc;
+    }
+    ctx.sync();
+    for (int idx = ctx.tid(); idx < (p0 + 1) * (KB_NB - 1); idx += ctx.nthreads()) {
+        const int r = idx % (p0 + 1), j = 1 + idx / (p0 + 1);
+        cd acc = czero();
+        for (int t = 0; t < j; ++t) acc = acc + Y[r + (size_t)t * ldy] * conj(hess_vt(W, ld, p0, p0 + j, t));
+        W[r + (size_t)(p0 + j) * ld] = W[r + (size_t)(p0 + j) * ld] - acc;
     }
     ctx.sync();
 }

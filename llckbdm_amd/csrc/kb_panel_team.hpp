@@ -432,6 +432,9 @@ KB_HD bool bidiag_panel_team(const C& ctx, PanelTeam<C>& tm, int n, cd* A, int l
 
 // ---------------------------------------------------------------------------------
 // Blocked Hessenberg panel (the derivation is at kb_eig.hpp: hess_panel).  One synchronisation of the team per column.
+// Rows r > p0 only (zlahr2's organisation): the rows above the panel take no part in its reflectors - their share of Y and
+// their panel columns follow in ONE product after the panel (kb_eig.hpp: hess_ytop_block / k_hess_ytop), so the pass over
+// A0 of column k reads (N - p0 - 1) x (N - k - 1) entries instead of N x (N - k - 1).
 // (Barriers as in bidiag_panel_team; the vector that is needed before its stores are drained is y_{j-1}: LDS.)
 template <class C>
 KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld, int p0, cd* tauh, cd* Y, int ldy,
@@ -453,10 +456,11 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
     cd* Tm = w1 + 8 * KB_NB;                                  // T, NB x NB upper triangular
     const int zrc = zr / C::WS;
     const bool writer = role == 0;
-    const int nrc = (N + C::WS - 1) / C::WS;
+    const int R0 = p0 + 1, NR = N - R0;                       // the panel's rows
+    const int nrc = (NR + C::WS - 1) / C::WS;
     const int nownc = team_own_count(nrc, role, T);
     for (int idx = tid; idx < KB_NB * KB_NB; idx += nt) Tm[idx] = czero();
-    for (int r = tid; r < N; r += nt) xc[r] = W_(r, p0);
+    for (int r = R0 + tid; r < N; r += nt) xc[r] = W_(r, p0);
     if (!tm.sync(ctx)) return false;       // (nobody stores the finished column over the raw one before every workgroup has read it)
     for (int j = 0; j < KB_NB; ++j) {
         const int k = p0 + j;
@@ -507,7 +511,7 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
                 if (lane == 0) w1[t] = acc;
             }
         });
-        for (int r = tid; r <= k; r += nt) W_(r, k) = xc[r];
+        for (int r = R0 + tid; r <= k; r += nt) W_(r, k) = xc[r];
         for (int r = k + 2 + tid; r < N; r += nt) W_(r, k) = xc[r];                 // (the entries this thread has just scaled)
         if (tid == 0) {
             W_(k + 1, k) = mk(beta, 0.0);
@@ -520,7 +524,7 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
         // ---- the corrections Y_j w1 of y and of the next column, for the owned rows (Y(:, j-1) from LDS)
         team_sweep8(ctx, nownc * C::WS,
             [&](int q, int g, cd& hp, cd& np) {
-                const int r = (role + (q / C::WS) * T) * C::WS + (q % C::WS);
+                const int r = R0 + (role + (q / C::WS) * T) * C::WS + (q % C::WS);
                 if (r >= N) return;
                 int t = g;
                 for (; t + KB_SWEEP_G < j; t += 2 * KB_SWEEP_G) {
@@ -538,20 +542,20 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
                 }
             },
             [&](int q, cd hp, cd np) {
-                const int r = (role + (q / C::WS) * T) * C::WS + (q % C::WS);
+                const int r = R0 + (role + (q / C::WS) * T) * C::WS + (q % C::WS);
                 if (r >= N) return;
                 sp[r] = hp;
                 sp[N + r] = np;
             });
-        // ---- y = tau (A0[:, k+1:] v - Y_j w1), all rows: the one pass over A0 of this column, owned chunks of rows
+        // ---- y = tau (A0[p0+1:, k+1:] v - Y_j w1): the one pass over A0 of this column, owned chunks of rows
         const int ncols = N - k - 1;
         const int xo = (j & 1) * 2 * N;       // two exchange regions in turn: a fast workgroup is one column ahead of the slowest reader at most
         for (int k0 = 0; k0 < nownc; k0 += zrc) {
             const int k1 = (k0 + zrc < nownc) ? k0 + zrc : nownc;
-            team_row_product(ctx, tm, N, ncols, &W_(0, k + 1), ld, xc + k + 1, zp, zr, k0, k1);
+            team_row_product(ctx, tm, NR, ncols, &W_(R0, k + 1), ld, xc + k + 1, zp, zr, k0, k1);
             ctx.sync_lds();
             for (int q = tid; q < (k1 - k0) * C::WS; q += nt) {
-                const int r = (role + (k0 + q / C::WS) * T) * C::WS + (q % C::WS);
+                const int r = R0 + (role + (k0 + q / C::WS) * T) * C::WS + (q % C::WS);
                 if (r >= N) continue;
                 const cd h = team_row_sum(zp, zr, q);
                 const cd y = tau * (h - sp[r]);
@@ -578,14 +582,14 @@ KB_HD bool hess_panel_team(const C& ctx, PanelTeam<C>& tm, int N, cd* W, int ld,
         }
         if (!tm.sync(ctx)) return false;
         if (T > 1)
-            for (int r = tid; r < N; r += nt) {
+            for (int r = R0 + tid; r < N; r += nt) {
                 const cd y = tm.get(xo + r);
                 Y_(r, j) = y;
                 yl[r] = y;
                 if (nextcol) xc[r] = tm.get(xo + N + r);
             }
         else
-            for (int r = tid; r < N; r += nt) {
+            for (int r = R0 + tid; r < N; r += nt) {
                 yl[r] = yn[r];
                 if (nextcol) xc[r] = xn[r];
             }

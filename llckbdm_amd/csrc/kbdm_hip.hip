@@ -578,7 +578,8 @@ int launch_eig(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
             const int ncol = ch.lmax - (pnl + 1) * KB_NB;
             {
                 KBracket kb(pl, ch, KBDM_K_HESS_Z, st, 1);
-                hipLaunchKernelGGL(k_hess_z, dim3((ncol + 63) / 64, ch.count), dim3(256), 0, st, pl->d_items, perm, pl->d_arena, pnl);
+                const int nzt = (ncol + 63) / 64, nyt = (pnl * KB_NB + 64) / 64;     // Z's tiles + the tiles of the rows above the panel
+                hipLaunchKernelGGL(k_hess_z, dim3(nzt + nyt, ch.count), dim3(256), 0, st, pl->d_items, perm, pl->d_arena, pnl, nzt);
             }
             {
                 KBracket kb(pl, ch, KBDM_K_HESS_UPDATE, st, 1);

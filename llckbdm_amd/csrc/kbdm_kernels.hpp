@@ -597,7 +597,9 @@ __global__ void __launch_bounds__(256) k_gemm(const KbItem* __restrict__ items, 
 
 // ------------------------------------------------------------------------------------
 // Blocked Hessenberg reduction of W (KB_BUF_P): for panel p = 0, 1, ... (host loop)
-//   k_hess_panel_team   a team of T >= 1 workgroups per item: NB reflectors, Y -> KB_BUF_Q; VT, MT -> KB_BUF_H (one pass over A0 per column)
+//   k_hess_panel_team   a team of T >= 1 workgroups per item: NB reflectors, Y -> KB_BUF_Q; VT, MT -> KB_BUF_H (one pass over the
+//                  rows of A0 below the panel's first row per column)
+//                  ... and, in the same launch, the rows above the panel: their Y = A0 VT and their entries of the panel's columns
 //   k_hess_z       all CUs: Z = A0^H VT - V MT for the columns right of the panel -> KB_BUF_H
 //   k_hess_update  all CUs: W[:, p0+NB:] -= [Y | V] [V | Z]^H  (FP64 MFMA tiles)
 // then k_hess finishes unblocked, extracts the work copy (KB_BUF_H) and ||H||_inf.
@@ -626,14 +628,55 @@ __global__ void __launch_bounds__(1024) k_hess_panel_team(const KbItem* __restri
         atomicOr(&status[item], KB_STAT_EIG_NOCONV);
 }
 
+// The rows above a panel (kb_eig.hpp, hess_ytop_block): Y(r, :) = A0(r, p0+1:) VT(p0+1:, :) for r <= p0 as FP64-MFMA tiles
+// (one workgroup = 64 rows x NB outputs, k = the columns right of p0; half of the tile's columns multiply zeros), then the
+// same rows of the panel's own columns 1 .. NB-1.  A workgroup reads and writes its own rows only.  (Tiles of k_hess_z's launch.)
+__device__ __forceinline__ void hess_ytop_tile(const KbItem& it, cd* arena, int panel, int tile, kb_tu_stage* s_op) {
+    const int n = it.l;
+    const int p0 = panel * KB_NB;
+    const int r0 = tile * 64;
+    if (r0 > p0) return;
+    cd* W = arena + it.off[KB_BUF_P];
+    cd* Y = arena + it.off[KB_BUF_Q];
+    const cd* VT = arena + it.off[KB_BUF_H] + (size_t)n * KB_NB + KB_NB * KB_NB;
+    const int K1 = n - p0 - 1, K1p = (K1 + KB_TU_KC - 1) / KB_TU_KC * KB_TU_KC;
+    mfma_tile_ks2<true, false, true>(
+        s_op,
+        [&](int i, int k) -> cd {
+            const int r = r0 + i;
+            return (r <= p0 && k < K1) ? W[r + (size_t)(p0 + 1 + k) * n] : czero();
+        },
+        [&](int i, int k) -> cd { return (i < KB_NB && k < K1) ? conj(VT[(p0 + 1 + k) + (size_t)i * n]) : czero(); },
+        [&](int i, int jx) -> cd* {
+            const int r = r0 + i;
+            return (r <= p0 && jx < KB_NB) ? &Y[r + (size_t)jx * n] : nullptr;
+        },
+        K1p / KB_TU_KC);
+    __threadfence_block();
+    __syncthreads();                                          // (the workgroup reads back its own rows of Y)
+    for (int e = threadIdx.x; e < 64 * (KB_NB - 1); e += 256) {
+        const int r = r0 + (e & 63), j = 1 + (e >> 6);
+        if (r > p0) continue;
+        cd acc = czero();
+        for (int t = 0; t < j; ++t) acc = acc + Y[r + (size_t)t * n] * conj(hess_vt(W, n, p0, p0 + j, t));
+        W[r + (size_t)(p0 + j) * n] = W[r + (size_t)(p0 + j) * n] - acc;
+    }
+}
+
 // Deferred left factor of a panel, all CUs:  Z(c, :) = A0(:, c)^H VT - V(c, :) MT  for the columns right of the
 // panel (kb_eig.hpp, hess_z_block).  One workgroup = 64 columns x NB outputs; A0 and VT go through LDS in chunks
 // of 16 rows (A0 is read once per panel here instead of once per column inside the panel).
+// Both products behind a panel in ONE launch: tiles [0, nzt) are Z's (64 columns each), the rest the rows above the panel.
 __global__ void __launch_bounds__(256) k_hess_z(const KbItem* __restrict__ items, const int* __restrict__ perm,
-                                                 cd* arena, int panel) {
+                                                 cd* arena, int panel, int nzt) {
     const KbItem it = items[perm[blockIdx.y]];
     const int n = it.l;
     if (panel >= bidiag_num_panels(n)) return;
+    __shared__ kb_tu_stage s_op[2];
+    if ((int)blockIdx.x >= nzt) {
+        hess_ytop_tile(it, arena, panel, blockIdx.x - nzt, s_op);
+        return;
+    }
     const int p0 = panel * KB_NB;
     const int cbase = p0 + KB_NB;
     const int c0 = cbase + blockIdx.x * 64;
@@ -648,7 +691,8 @@ __global__ void __launch_bounds__(256) k_hess_z(const KbItem* __restrict__ items
     // along r: k-fastest staging.  Only 32 of the tile's 64 columns exist (t < NB): half the MFMAs multiply zeros, still
     // several times the rate of the vector-FMA tiles this replaces (3.3 TFLOP/s on the C4 batch).
     const int K1 = n - p0 - 1, K1p = (K1 + KB_TU_KC - 1) / KB_TU_KC * KB_TU_KC;
-    mfma_tile_kx<true, true>(
+    mfma_tile_ks2<true, true, true>(
+        s_op,
         [&](int i, int k) -> cd {
             const int c = c0 + i;
             if (c >= n) return czero();

@@ -191,6 +191,7 @@ int hs_eig(const double* W_in, int n, double* mu_out, double* P_out) {
                     hess_panel_team(c, tm, n, W.data(), n, p0, th.data() + p0, Yp.data(), n, VTp.data(), n, MTp.data(), HS_ZR);
                 });
             }
+            hess_ytop_block(ctx, n, W.data(), n, p0, VTp.data(), n, Yp.data(), n);
             hess_z_block(ctx, n, W.data(), n, p0, VTp.data(), n, MTp.data(), Zp.data(), n, p0 + KB_NB, n);
             for (int c = p0 + KB_NB; c < n; ++c)
                 for (int r = 0; r < n; ++r) {
