@@ -250,6 +250,17 @@ def hankel_alone(work, members=512):
                         "stream: the same kernel alone under rocprofv3 (tools/hankel_bw.sh) reads 4.27 TB/s"}
 
 
+def pmc_c3():
+    """MFMA busy fraction of the rank-64 updates on C3 from the newest committed PMC pass (not measured by this run)."""
+    import glob
+    fns = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_north_star_kernels_c3.json")))
+    if not fns:
+        return None
+    d = json.load(open(fns[-1]))
+    return {"k_trail_update": d["k_trail_update"].get("pmc_mfma_utilisation"), "k_hess_update": d["k_hess_update"].get("pmc_mfma_utilisation"),
+            "source": "profiles/" + os.path.basename(fns[-1])}
+
+
 def clean_profile(eng, work, reps=3):
     """One ensemble at a time, the GPU to itself, with the library's per-kernel HIP-event timers on (KBDM_MODE_KERNEL_TIMERS:
     events on the stream each kernel runs on, around every launch of the timed kernel classes): the basis of the roofline
@@ -551,11 +562,25 @@ def main():
                         hk = None
                         if name == "C3":
                             hk = hankel_alone(w[0])
+                            try:
+                                # north_star's "MFMA utilisation in the SVD panel update" where the launches fill the chip:
+                                # one C3 ensemble at a time with the per-kernel HIP-event timers on
+                                cst, ckm = clean_profile(eng, w[0][:3], reps=1)
+                                sg3 = np.atleast_2d(w[0][0])
+                                n0c3 = eng.cached_plan(sg3.shape[0], sg3.shape[1], w[0][1], w[0][2], w[0][2], 1, 0.0, DWELL).lane0_members()
+                                ck, _ = build_rooflines(w[0][2], n0c3, cst, ckm)
+                                c3_mfma = {r["kernel"]: {"frac_of_fp64_matrix_peak": r["frac"], "TFLOPs": r["achieved"], "avg_ms": r["avg_ms"],
+                                                         "launches": r["launches"]}
+                                           for r in ck if r["kernel"] in ("k_trail_update", "k_hess_update")}
+                            except Exception as e:
+                                c3_mfma = {"error": repr(e)}
                         others[name] = {"workload": WORKLOADS[name], "value": len(w[0][2]) * steps_o / to, "unit": "solves/s", "hankel_build": hk,
                                         "ms_per_step": 1e3 * to / steps_o, "steps": steps_o, "ensembles_in_flight": fl_o,
                                         "members": int(len(w[0][2])), "members_ok": int((chk.status == 0).sum()),
                                         "eig_fallbacks": eng._slots[0].plans and max(pl.eig_fallbacks() for pl in eng._slots[0].plans.values()),
                                         "timed": "host -> host through Engine.submit"}
+                        if name == "C3":
+                            others[name]["rank64_updates"] = c3_mfma
                     except Exception as e:       # informational lines: never lose the headline over them
                         others[name] = {"error": repr(e)}
                     eng.clear_plan_cache()
@@ -612,9 +637,14 @@ def main():
                     "mfma_util_svd_panel_update": None if tu is None else tu["frac"],
                     "mfma_util_hess_update": None if hu is None else hu["frac"],
                     "hankel_build_GBps_c2_launch": None if hk2 is None else hk2["achieved"],
+                    "mfma_util_svd_panel_update_c3": ((others.get("C3") or {}).get("rank64_updates") or {}).get("k_trail_update"),
+                    "mfma_util_hess_update_c3": ((others.get("C3") or {}).get("rank64_updates") or {}).get("k_hess_update"),
+                    "pmc_c3": pmc_c3(),
                     "note": "MFMA utilisation = algorithmic flops of the rank-64 update launches / their HIP-event time / 78.6 "
-                            "TFLOP/s, over ALL launches of lane 0 in the clean pass; the Hankel build on a chip-filling launch: "
-                            "other_configs.C3.hankel_build"}
+                            "TFLOP/s, over ALL launches of lane 0 in the clean pass: C2's launches cover 32 members (sub-chip: "
+                            "the last panels launch 128 workgroups), C3's (512 members) fill the chip; pmc_c3: "
+                            "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) from the committed rocprofv3 pass "
+                            "(tools/mfma_c3.sh); the Hankel build on a chip-filling launch: other_configs.C3.hankel_build"}
         if roofline is None:
             roofline = {"kernel": None, "bound": "mfma", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                         "traffic": None, "note": "no clean pass in this mode (N > 1): see the N = 1 line"}

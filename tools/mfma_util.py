@@ -6,7 +6,7 @@ tools/collect_profiles.sh (workload C2):
     trace of the normal (overlapped) run, against the 78.6 TFLOP/s FP64 matrix peak;
   * HBM rate of the Hankel build k_hankel: algorithmic bytes (16 m^2 written + 32 m read per member: inside the
     pipeline only U^{p-1} is materialised) / launch duration, against 8 TB/s.
-usage: python tools/mfma_util.py <kernel_trace.csv> [<counter_collection.csv>]"""
+usage: python tools/mfma_util.py <kernel_trace.csv> [<counter_collection.csv> [C3]]   (C3: the trace is of bench.py --workload C3)"""
 import csv
 import json
 import sys
@@ -14,6 +14,8 @@ import sys
 PEAK_TFLOPS = 78.6
 NB, NX = 32, 64
 MS = list(range(100, 401, 2))
+if len(sys.argv) > 3 and sys.argv[3] == "C3":
+    MS = [512] * 1024
 
 
 def npanels(m):
