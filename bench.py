@@ -233,6 +233,7 @@ def hankel_alone(work, members=512):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+    rank64 = None
     try:
         best = None
         for _ in range(3):
@@ -241,13 +242,23 @@ def hankel_alone(work, members=512):
             assert h.plan.lane0_members() == len(m)
             ms_h = h.plan.stage_ms()["k_hankel"]
             best = ms_h if best is None else min(best, ms_h)
+        try:
+            # north_star's "MFMA utilisation in the SVD panel update" on launches that fill the chip, with nothing else on the
+            # GPU (with two lanes the other lane's panel workgroups sit in front of an update's tiles and its events time them)
+            cst, ckm = clean_profile(e1, (sig, idx, m), reps=1)
+            ck, _ = build_rooflines(m, len(m), cst, ckm)
+            rank64 = {r["kernel"]: {"frac_of_fp64_matrix_peak": r["frac"], "TFLOPs": r["achieved"], "avg_ms": r["avg_ms"],
+                                    "launches": r["launches"], "members_per_launch": int(len(m))}
+                      for r in ck if r["kernel"] in ("k_trail_update", "k_hess_update")}
+        except Exception as e:
+            rank64 = {"error": repr(e)}
     finally:
         e1.close()
     hb = sum(16.0 * int(x) * int(x) + 16.0 * (2 * int(x) - 1) for x in m)
     return {"kernel": "k_hankel", "members": int(len(m)), "bytes": hb, "ms": best, "GBps": hb / (best * 1e-3) / 1e9,
             "frac_of_hbm_peak": hb / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "measured": "one lane, nothing else on the GPU; best of 3 launches (HIP events on the launch's stream); a write-only "
-                        "stream: the same kernel alone under rocprofv3 (tools/hankel_bw.sh) reads 4.27 TB/s"}
+                        "stream: the same kernel alone under rocprofv3 (tools/hankel_bw.sh) reads 4.27 TB/s"}, rank64
 
 
 def pmc_c3():
@@ -561,19 +572,7 @@ def main():
                         chk = eng.submit(*w[0][:3], w[0][2], p=1, q=0.0, dwell=DWELL).result(check=False)
                         hk = None
                         if name == "C3":
-                            hk = hankel_alone(w[0])
-                            try:
-                                # north_star's "MFMA utilisation in the SVD panel update" where the launches fill the chip:
-                                # one C3 ensemble at a time with the per-kernel HIP-event timers on
-                                cst, ckm = clean_profile(eng, w[0][:3], reps=1)
-                                sg3 = np.atleast_2d(w[0][0])
-                                n0c3 = eng.cached_plan(sg3.shape[0], sg3.shape[1], w[0][1], w[0][2], w[0][2], 1, 0.0, DWELL).lane0_members()
-                                ck, _ = build_rooflines(w[0][2], n0c3, cst, ckm)
-                                c3_mfma = {r["kernel"]: {"frac_of_fp64_matrix_peak": r["frac"], "TFLOPs": r["achieved"], "avg_ms": r["avg_ms"],
-                                                         "launches": r["launches"]}
-                                           for r in ck if r["kernel"] in ("k_trail_update", "k_hess_update")}
-                            except Exception as e:
-                                c3_mfma = {"error": repr(e)}
+                            hk, c3_mfma = hankel_alone(w[0])
                         others[name] = {"workload": WORKLOADS[name], "value": len(w[0][2]) * steps_o / to, "unit": "solves/s", "hankel_build": hk,
                                         "ms_per_step": 1e3 * to / steps_o, "steps": steps_o, "ensembles_in_flight": fl_o,
                                         "members": int(len(w[0][2])), "members_ok": int((chk.status == 0).sum()),
@@ -642,7 +641,8 @@ def main():
                     "pmc_c3": pmc_c3(),
                     "note": "MFMA utilisation = algorithmic flops of the rank-64 update launches / their HIP-event time / 78.6 "
                             "TFLOP/s, over ALL launches of lane 0 in the clean pass: C2's launches cover 32 members (sub-chip: "
-                            "the last panels launch 128 workgroups), C3's (512 members) fill the chip; pmc_c3: "
+                            "the last panels launch 128 workgroups); the _c3 figures: 512 members of C3 on a one-lane context "
+                            "(launches that fill the chip, nothing else on the GPU); pmc_c3: "
                             "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) from the committed rocprofv3 pass "
                             "(tools/mfma_c3.sh); the Hankel build on a chip-filling launch: other_configs.C3.hankel_build"}
         if roofline is None:

@@ -545,8 +545,10 @@ int launch_svd(kbdm_plan* pl, Chunk& ch, StageTimer* tm) {
                                    pl->d_arena, pnl);
             }
         }
-        const int sm = smem_fac(ch.mmax, ctx->nt_fac);
+        int sm = smem_fac(ch.mmax, ctx->nt_fac);
         if (sm > LDS_MAX) return fail(KBDM_E_NOMEM, "m too large for the bidiagonalisation scratch");
+        // room for the block behind the panels (fewer than NB + NX columns), which k_svd_fac then reduces in LDS
+        if (npan > 0) sm = std::max(sm, std::min(LDS_MAX, KB_RED_BYTES + bidiag_tail_lds_bytes(KB_NB + KB_NX - 1, ctx->nt_fac / 64, 64)));
         hipLaunchKernelGGL(k_svd_fac, dim3(ch.count), dim3(ctx->nt_fac), sm, st, pl->d_items, perm, pl->d_arena,
                            pl->d_varena, sm, npan > 0 ? 1 : 0);
         if (tm) { int r = tm->mark(); if (r) return r; }

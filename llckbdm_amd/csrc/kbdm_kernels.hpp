@@ -312,7 +312,12 @@ __global__ void __launch_bounds__(1024) k_svd_fac(const KbItem* __restrict__ ite
     double* e = dv + KB_V_E * it.vstride;
     cd* tauq = reinterpret_cast<cd*>(dv + KB_V_TAUQ * it.vstride);
     cd* taup = reinterpret_cast<cd*>(dv + KB_V_TAUP * it.vstride);
-    bidiag(ctx, m, A, m, d, e, tauq, taup, UR, m, blocked ? bidiag_num_panels(m) * KB_NB : 0);
+    const int k0 = blocked ? bidiag_num_panels(m) * KB_NB : 0;
+    // behind the panels fewer than NB + NX columns are left: that block is reduced in LDS (the same arithmetic)
+    if (k0 > 0 && bidiag_tail_lds_bytes(m - k0, blockDim.x >> 6, 64) <= ctx.scratch_bytes())
+        bidiag_tail_lds(ctx, m, A, m, d, e, tauq, taup, UR, m, k0);
+    else
+        bidiag(ctx, m, A, m, d, e, tauq, taup, UR, m, k0);
 }
 
 // Explicit unitary factors, columns spread over gridDim.x workgroups per item and matrix.
