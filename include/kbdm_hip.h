@@ -223,6 +223,13 @@ int kbdm_rmse_batch(kbdm_ctx* ctx, const double* data, int N, double dwell, cons
  * out[n].  Needs at least 2 classes and at most n - 1 (sklearn's precondition). */
 int kbdm_silhouette_samples(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* labels, double* out);
 
+/* The same for nfits labelings of the same samples in one call (the sweep scores every fit: llckbdm.py:291 inside the loop
+ * at :104-110): labels[nfits * n], out[nfits * n]; the same bits as one kbdm_silhouette_samples call per labeling.  A
+ * labeling outside sklearn's precondition (fewer than 2 or more than n - 1 label values) gets valid_out[f] = 0 and zeros
+ * instead of an error; valid_out may be null. */
+int kbdm_silhouette_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* labels, int nfits, double* out,
+                          int32_t* valid_out);
+
 /* HDBSCAN* for every value of `min_samples` of the clustering sweep at once: replaces the loop of
  * `hdbscan.HDBSCAN(min_samples=k).fit(X).labels_` at llckbdm/llckbdm.py:104-110,280-283 (Euclidean, alpha 1,
  * excess of mass, no single-cluster result; semantics of scikit-learn's HDBSCAN: the point itself counts towards

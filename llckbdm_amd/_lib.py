@@ -65,6 +65,7 @@ SYMBOLS = {
     "kbdm_plan_ab_stats": (c_int, [_P, _P, c_int]),
     "kbdm_rmse_batch": (c_int, [_P, _P, c_int, c_double, _P, _P, c_int, _P]),
     "kbdm_silhouette_samples": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "kbdm_silhouette_sweep": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "kbdm_hdbscan_sweep": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "kbdm_core_distances": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P]),
     "kbdm_hdbscan_labels_from_mst": (c_int, [c_int, _P, _P, _P, c_int, _P]),

@@ -1688,6 +1688,68 @@ int kbdm_silhouette_samples(kbdm_ctx* ctx, const double* X, int n, int dim, cons
     return r;
 }
 
+int kbdm_silhouette_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int32_t* labels, int nfits, double* out,
+                          int32_t* valid_out) {
+    if (!ctx || !X || !labels || !out || n < 2 || dim < 1 || dim > KB_SIL_MAXDIM || nfits < 1) return fail(KBDM_E_INVALID, "bad silhouette arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    // per labeling: classes = sorted distinct labels, samples sorted by class (stable) - as kbdm_silhouette_samples does
+    std::vector<int> order((size_t)nfits * n), cls((size_t)nfits * n), cstart, coff(nfits), nclass(nfits);
+    const int nthreads = std::max(1, std::min(nfits, std::min(16, (int)std::thread::hardware_concurrency())));
+    std::vector<std::vector<int>> cs(nfits);
+    {
+        std::vector<std::thread> pool;
+        for (int tix = 0; tix < nthreads; ++tix)
+            pool.emplace_back([&, tix]() {
+                for (int f = tix; f < nfits; f += nthreads) {
+                    const int32_t* lab = labels + (size_t)f * n;
+                    int* ord = order.data() + (size_t)f * n;
+                    int* cl = cls.data() + (size_t)f * n;
+                    std::iota(ord, ord + n, 0);
+                    std::stable_sort(ord, ord + n, [&](int a, int b) { return lab[a] < lab[b]; });
+                    int nc = 0;
+                    for (int k = 0; k < n; ++k) {
+                        if (k == 0 || lab[ord[k]] != lab[ord[k - 1]]) { cs[f].push_back(k); ++nc; }
+                        cl[k] = nc - 1;
+                    }
+                    cs[f].push_back(n);
+                    nclass[f] = (nc < 2 || nc > n - 1) ? 0 : nc;      // sklearn's precondition: such a labeling has no silhouettes
+                }
+            });
+        for (auto& th : pool) th.join();
+    }
+    for (int f = 0; f < nfits; ++f) {
+        coff[f] = (int)cstart.size();
+        cstart.insert(cstart.end(), cs[f].begin(), cs[f].end());
+        if (valid_out) valid_out[f] = nclass[f] ? 1 : 0;
+    }
+    double *d_x = nullptr, *d_o = nullptr;
+    int *d_ord = nullptr, *d_cls = nullptr, *d_cs = nullptr, *d_coff = nullptr, *d_nc = nullptr;
+    hipStream_t st = ctx->stream;
+    int r = KBDM_OK;
+    do {
+        if (hipMalloc(&d_x, sizeof(double) * n * dim) != hipSuccess || hipMalloc(&d_o, sizeof(double) * (size_t)nfits * n) != hipSuccess ||
+            hipMalloc(&d_ord, sizeof(int) * (size_t)nfits * n) != hipSuccess || hipMalloc(&d_cls, sizeof(int) * (size_t)nfits * n) != hipSuccess ||
+            hipMalloc(&d_cs, sizeof(int) * cstart.size()) != hipSuccess || hipMalloc(&d_coff, sizeof(int) * nfits) != hipSuccess ||
+            hipMalloc(&d_nc, sizeof(int) * nfits) != hipSuccess) {
+            r = fail(KBDM_E_NOMEM, "hipMalloc (silhouette sweep)");
+            break;
+        }
+        hipMemcpyAsync(d_x, X, sizeof(double) * n * dim, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_ord, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_cls, cls.data(), sizeof(int) * cls.size(), hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_cs, cstart.data(), sizeof(int) * cstart.size(), hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_coff, coff.data(), sizeof(int) * nfits, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_nc, nclass.data(), sizeof(int) * nfits, hipMemcpyHostToDevice, st);
+        hipMemsetAsync(d_o, 0, sizeof(double) * (size_t)nfits * n, st);
+        hipLaunchKernelGGL(k_silhouette_sweep, dim3((n + KB_SIL_TILE - 1) / KB_SIL_TILE, nfits), dim3(KB_SIL_TILE), 0, st, d_x, n, dim,
+                           d_ord, d_cls, d_cs, d_coff, d_nc, d_o);
+        hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)nfits * n, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "silhouette kernel failed"); break; }
+    } while (0);
+    hipFree(d_x); hipFree(d_o); hipFree(d_ord); hipFree(d_cls); hipFree(d_cs); hipFree(d_coff); hipFree(d_nc);
+    return r;
+}
+
 int kbdm_hdbscan_labels_from_mst(int n, const int32_t* a, const int32_t* b, const double* w, int min_cluster_size,
                                  int32_t* labels_out) {
     if (n < 1 || !labels_out || (n > 1 && (!a || !b || !w)) || min_cluster_size < 2) return fail(KBDM_E_INVALID, "bad mst arguments");
@@ -1788,7 +1850,20 @@ int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int
         hipMemcpyAsync(d_x, X, sizeof(double) * n * dim, hipMemcpyHostToDevice, st);
         hipMemcpyAsync(d_ms, min_samples, sizeof(int) * nfits, hipMemcpyHostToDevice, st);
         launch_knn(g, st, d_x, n, dim, K, d_knn, d_lo, d_skip);
-        hipLaunchKernelGGL(k_prim_mst, dim3(nfits), dim3(1024), 0, st, d_x, n, dim, K, d_knn, d_ms, d_best, d_core, d_src, d_edges);
+        // Prim per fit: the register-resident form for the reference's 4-dimensional samples while a thread's share fits
+        // its registers (n <= 20480: a C2 ensemble pools about 20 000 lines), the general form beyond
+        const size_t psm = sizeof(int) * (size_t)n;
+        if (dim == 4 && n <= 1024 * 6) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_mst_reg<6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
+            hipLaunchKernelGGL(k_prim_mst_reg<6>, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_edges);
+        } else if (dim == 4 && n <= 1024 * 12) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_mst_reg<12>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
+            hipLaunchKernelGGL(k_prim_mst_reg<12>, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_edges);
+        } else if (dim == 4 && n <= 1024 * 20) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_mst_reg<20>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
+            hipLaunchKernelGGL(k_prim_mst_reg<20>, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_edges);
+        } else
+            hipLaunchKernelGGL(k_prim_mst, dim3(nfits), dim3(1024), 0, st, d_x, n, dim, K, d_knn, d_ms, d_best, d_core, d_src, d_edges);
         hipMemcpyAsync(edges.data(), d_edges, sizeof(KbEdge) * edges.size(), hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "hdbscan kernels failed"); break; }
     } while (0);

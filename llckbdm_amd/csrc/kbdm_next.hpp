@@ -110,6 +110,68 @@ __global__ void __launch_bounds__(KB_SIL_TILE) k_silhouette(const double* __rest
     }
 }
 
+
+// The silhouettes of SEVERAL labelings of the same samples in one launch (the clustering sweep scores every fit,
+// llckbdm.py:291 inside the loop at :104-110): grid.y = labeling.  The samples stay in their original order in memory
+// (one upload); labeling f brings its own stable sort by class - order[f * n + k] = sample at sorted position k - with the
+// class of every position and the class ranges (cstart at coff[f], nclass[f] of them).  Thread k takes sorted position k;
+// the sums run over the classes and, inside a class, over the sorted positions exactly as in k_silhouette: the same bits
+// as one k_silhouette call per labeling.  A labeling with nclass[f] = 0 is skipped (sklearn's precondition fails).
+__global__ void __launch_bounds__(KB_SIL_TILE) k_silhouette_sweep(const double* __restrict__ x, int n, int dim,
+                                                                   const int* __restrict__ order_all, const int* __restrict__ cls_all,
+                                                                   const int* __restrict__ cstart_all, const int* __restrict__ coff,
+                                                                   const int* __restrict__ nclass_all, double* __restrict__ out_all) {
+    const int f = blockIdx.y;
+    const int nclass = nclass_all[f];
+    if (nclass == 0) return;
+    const int* __restrict__ order = order_all + (size_t)f * n;
+    const int* __restrict__ cls = cls_all + (size_t)f * n;
+    const int* __restrict__ cstart = cstart_all + coff[f];
+    __shared__ double tile[KB_SIL_TILE * KB_SIL_MAXDIM];
+    const int i = blockIdx.x * KB_SIL_TILE + threadIdx.x;
+    const bool live = i < n;
+    const int me = live ? order[i] : 0;
+    double xi[KB_SIL_MAXDIM];
+#pragma unroll
+    for (int d = 0; d < KB_SIL_MAXDIM; ++d) xi[d] = (live && d < dim) ? x[(size_t)me * dim + d] : 0.0;
+    const int mine = live ? cls[i] : -1;
+    double a = 0.0, b = 1.79769313486231570815e308;
+    for (int c = 0; c < nclass; ++c) {
+        const int j0 = cstart[c], j1 = cstart[c + 1];
+        double sum = 0.0;
+        for (int jb = j0; jb < j1; jb += KB_SIL_TILE) {
+            const int cnt = (j1 - jb < KB_SIL_TILE) ? j1 - jb : KB_SIL_TILE;
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < cnt * dim; idx += KB_SIL_TILE) {
+                const int j = idx / dim, d = idx - j * dim;
+                tile[idx] = x[(size_t)order[jb + j] * dim + d];
+            }
+            __syncthreads();
+            if (live) {
+                for (int j = 0; j < cnt; ++j) {
+                    double d2 = 0.0;
+#pragma unroll
+                    for (int d = 0; d < KB_SIL_MAXDIM; ++d)
+                        if (d < dim) { const double df = xi[d] - tile[j * dim + d]; d2 = fma(df, df, d2); }
+                    sum += sqrt(d2);
+                }
+            }
+        }
+        const int sz = j1 - j0;
+        if (c == mine) a = (sz > 1) ? sum / (double)(sz - 1) : 0.0;
+        else if (sz > 0) { const double mean = sum / (double)sz; b = mean < b ? mean : b; }
+    }
+    if (live) {
+        const int sz = cstart[mine + 1] - cstart[mine];
+        double s = 0.0;
+        if (sz > 1 && nclass > 1) {
+            const double mx = a > b ? a : b;
+            s = (mx > 0.0) ? (b - a) / mx : 0.0;
+        }
+        out_all[(size_t)f * n + me] = s;
+    }
+}
+
 }  // namespace kb
 
 namespace kb {
@@ -246,6 +308,115 @@ __global__ void __launch_bounds__(1024) k_prim_mst(const double* __restrict__ xs
                 if (red_v[wv] < bv || (red_v[wv] == bv && red_i[wv] < bi)) { bv = red_v[wv]; bi = red_i[wv]; }
             edges[step] = KbEdge{src[bi], bi, bv};
             best[bi] = -1.0;
+            cur_s = bi;
+        }
+        __syncthreads();
+    }
+}
+
+
+// The same algorithm - the same relaxation, the same argmin, the same edges in the same order - for 4-dimensional samples
+// (the reference's transformed line lists) and n <= 1024 NS, with the per-fit state where it is cheap to reach: thread t
+// keeps best and core of its samples t, t + 1024, ... in REGISTERS (slot index static: the loops are unrolled), the source
+// of a sample's best edge sits in LDS (n ints); per step a thread only streams the coordinates of its samples that are
+// still outside the tree (two at a time, four 16-byte loads in flight; a sample inside the tree reads the new vertex's
+// row instead: one hot cache line).  Every thread does the final argmin over the wavefronts' candidates itself, the owner
+// of the winner records the edge and publishes the new vertex: two barriers per step, no serial tail.
+// One step of k_prim_mst costs 16-20 us at n = 20 000 (every access a dependent trip to the L2); this form streams only
+// the coordinates: 32 B per outside sample and step.
+typedef double kb_prim_d2 __attribute__((ext_vector_type(2)));
+template <int NS>
+__global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict__ xs, int n, int K,
+                                                        const double* __restrict__ knn, const int* __restrict__ min_samples,
+                                                        KbEdge* __restrict__ edges_all) {
+    constexpr int NT = 1024;
+    const int fit = blockIdx.x;
+    const int ks = min_samples[fit];
+    KbEdge* edges = edges_all + (size_t)fit * (n - 1);
+    const int t = threadIdx.x;
+    const double inf = 1.79769313486231570815e308;
+    extern __shared__ int kb_prim_src[];                       // n ints
+    __shared__ double red_v[16];
+    __shared__ int red_i[16];
+    __shared__ double xnew[5];                                 // the new vertex: coordinates, core distance
+    __shared__ int cur_s;
+    const kb_prim_d2* __restrict__ x2 = reinterpret_cast<const kb_prim_d2*>(xs);
+    double bestr[NS], corer[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = t + s * NT;
+        corer[s] = (i < n) ? knn[(size_t)i * K + ks - 1] : 0.0;
+        bestr[s] = (i < n && i != 0) ? inf : -1.0;            // best < 0: in the tree (or no such sample)
+    }
+    for (int i = t; i < n; i += NT) kb_prim_src[i] = 0;
+    if (t == 0) {
+        const kb_prim_d2 a = x2[0], b = x2[1];
+        xnew[0] = a.x; xnew[1] = a.y; xnew[2] = b.x; xnew[3] = b.y; xnew[4] = corer[0];
+        cur_s = 0;
+    }
+    __syncthreads();
+    for (int step = 0; step < n - 1; ++step) {
+        const int cur = cur_s;
+        const double c0 = xnew[0], c1 = xnew[1], c2 = xnew[2], c3 = xnew[3], ccur = xnew[4];
+        double mv = inf;
+        int mi = 0x7fffffff;
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += 2) {
+            kb_prim_d2 xa[2], xb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = s0 + u;
+                if (s < NS) {
+                    const int i = t + s * NT;
+                    const size_t row = (bestr[s] >= 0.0) ? (size_t)i : (size_t)cur;
+                    xa[u] = x2[2 * row];
+                    xb[u] = x2[2 * row + 1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = s0 + u;
+                if (s < NS) {
+                    const int i = t + s * NT;
+                    double b = bestr[s];
+                    const bool act = b >= 0.0;
+                    double df = xa[u].x - c0;                  // (the same operations in the same order as k_prim_mst: an fma chain from 0)
+                    double d2 = fma(df, df, 0.0);
+                    df = xa[u].y - c1; d2 = fma(df, df, d2);
+                    df = xb[u].x - c2; d2 = fma(df, df, d2);
+                    df = xb[u].y - c3; d2 = fma(df, df, d2);
+                    double w = sqrt(d2);
+                    w = fmax(w, fmax(corer[s], ccur));
+                    if (act && w < b) { b = w; kb_prim_src[i] = cur; }
+                    bestr[s] = act ? b : bestr[s];
+                    if (act && b < mv) { mv = b; mi = i; }
+                }
+            }
+        }
+        const int mi0 = mi;
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(mv, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
+            if (ov < mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; }
+        }
+        if ((t & 63) == 0) { red_v[t >> 6] = mv; red_i[t >> 6] = mi; }
+        __syncthreads();
+        double bv = red_v[0];
+        int bi = red_i[0];
+#pragma unroll
+        for (int wv = 1; wv < NT / 64; ++wv) {
+            const double v = red_v[wv];
+            const int ix = red_i[wv];
+            if (v < bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+        }
+        if (mi0 == bi) {                                       // the owner of the winner (an outside sample exists while step < n - 1)
+            edges[step] = KbEdge{kb_prim_src[bi], bi, bv};
+            const kb_prim_d2 a = x2[2 * (size_t)bi], b = x2[2 * (size_t)bi + 1];
+            double cc = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (bi == t + s * NT) { cc = corer[s]; bestr[s] = -1.0; }
+            xnew[0] = a.x; xnew[1] = a.y; xnew[2] = b.x; xnew[3] = b.y; xnew[4] = cc;
             cur_s = bi;
         }
         __syncthreads();

@@ -532,6 +532,17 @@ class Engine:
                                                     _lib.ptr(out)))
         return out
 
+    def silhouette_sweep(self, X, labels):
+        """`silhouette_samples` for every row of `labels` (nfits x n) in one GPU call: (silhouettes[nfits, n], valid[nfits]);
+        the same bits as one call per row; a row outside sklearn's precondition comes back with valid = False."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        labels = np.ascontiguousarray(np.atleast_2d(labels), dtype=np.int32)
+        out = np.empty(labels.shape, dtype=np.float64)
+        valid = np.empty(labels.shape[0], dtype=np.int32)
+        _lib.check(self.lib.kbdm_silhouette_sweep(self.ctx, _lib.ptr(X), X.shape[0], X.shape[1], _lib.ptr(labels), labels.shape[0],
+                                                  _lib.ptr(out), _lib.ptr(valid)))
+        return out, valid.astype(bool)
+
     def hdbscan_sweep(self, X, min_samples_list, min_cluster_size=5):
         """HDBSCAN* labels for every `min_samples` of the list in one GPU call (the clustering sweep of
         llckbdm.py:104-110): one pass of k-nearest-neighbour distances shared by all fits, one Prim MST per fit

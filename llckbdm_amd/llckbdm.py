@@ -83,19 +83,26 @@ def llc_kbdm(data, dwell, m_range, p=1, l=None, q=0.0, engine=None, clusterer="g
     sweep = list(range(int(np.ceil(0. * m_range_size + 1)), m_range_size))           # llckbdm.py:104
     # min_samples cannot exceed the number of pooled lines (the packages raise there; such fits have no clusters)
     labels_all = None
+    sil_all = {}
     if clusterer == "gpu" and len(transformed_line_list) >= 2:
         fits = [k for k in sweep if k <= len(transformed_line_list)]
         labels_all = {}
         if fits:                     # every fit on the GPU, whatever min_samples (no host clusterer behind the caller's back)
             got, _ = eng.hdbscan_sweep(transformed_line_list, fits, MIN_CLUSTER_SIZE)
             labels_all.update(zip(fits, got))
+            # ... and the silhouettes of every fit in one call as well (an engine without the batched entry scores fit by fit)
+            sweep_sil = getattr(eng, "silhouette_sweep", None)
+            if sweep_sil is not None:
+                sil, ok = sweep_sil(transformed_line_list, np.asarray(got))
+                sil_all = {k: (sil[f] if ok[f] else None) for f, k in enumerate(fits)}
     for min_samples in sweep:
         logger.debug('HDBSCAN with min_samples = %d', min_samples)
         if clusterer == "gpu" and (labels_all is None or min_samples not in labels_all):
             continue
         clustering_result = _cluster_line_lists(samples=samples, transformed_samples=transformed_line_list,
                                                 min_samples=min_samples, engine=eng, clusterer=clusterer,
-                                                labels=None if labels_all is None else labels_all[min_samples])
+                                                labels=None if labels_all is None else labels_all[min_samples],
+                                                sil=sil_all.get(min_samples))
         if clustering_result.num_clusters > 0:
             clustering_results.append(clustering_result)
     summarized_line_lists = [cl_result.summarized_line_list for cl_result in clustering_results]
@@ -170,7 +177,7 @@ def _inverse_transform_line_lists(transformed_line_lists, dwell):
     return np.column_stack((A, T2, F, PH))
 
 
-def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, clusterer="gpu", labels=None):
+def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, clusterer="gpu", labels=None, sil=None):
     """One density clustering of the pooled lines, the mean silhouette of every cluster and the summarised line
     list.  Same result type and field meaning as the reference's llckbdm.py:264-321; the work is organised around
     ONE stable sort of the labels (cluster index sets are slices of it, per-cluster means are segmented sums).  The
@@ -192,7 +199,8 @@ def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, 
     # index set (searchsorted: start == end), never a wrong segment
     starts = np.searchsorted(sorted_labels, np.arange(num_clusters + 1))
     members = [(np.sort(order[starts[k]:starts[k + 1]]),) for k in range(num_clusters)]   # np.nonzero-style tuples
-    sil = (engine or default_engine()).silhouette_samples(transformed_samples, labels)
+    if sil is None:                                            # (llc_kbdm hands over the sweep's batched silhouettes)
+        sil = (engine or default_engine()).silhouette_samples(transformed_samples, labels)
     with np.errstate(invalid="ignore", divide="ignore"):
         mean_sil = np.array([np.average(sil[ix]) if len(ix) else np.nan for (ix,) in members])   # llckbdm.py:299-301
     clustered = np.empty(num_clusters, dtype=object)

@@ -178,3 +178,20 @@ def test_core_distances_random_points_and_sweep_beyond_one_pass(eng):
         ref = np.empty(len(X), dtype=np.int32)
         lib.kbdm_hdbscan_labels_from_mst(len(X), _lib.ptr(a), _lib.ptr(b), _lib.ptr(w), 5, _lib.ptr(ref))
         assert np.array_equal(labels[f], ref), k
+
+
+def test_silhouette_sweep_equals_one_call_per_labeling(eng):
+    """The batched silhouettes (C ABI kbdm_silhouette_sweep, what llc_kbdm scores the sweep with) are the SAME BITS as one
+    kbdm_silhouette_samples call per labeling, in the samples' original order; a labeling outside sklearn's precondition
+    (one label value only) comes back marked invalid instead of raising."""
+    rng = np.random.default_rng(17)
+    X = _data(rng, 1200, 6, 0.3, 150)
+    labels, _ = eng.hdbscan_sweep(X, [1, 3, 8, 20, 60])
+    labs = np.concatenate([labels, np.zeros((1, len(X)), np.int32), rng.integers(-1, 9, (1, len(X))).astype(np.int32)])
+    sil, ok = eng.silhouette_sweep(X, labs)
+    assert sil.shape == labs.shape and ok.tolist() == [True] * 5 + [False, True]
+    for f in range(len(labs)):
+        if ok[f]:
+            assert np.array_equal(sil[f], eng.silhouette_samples(X, labs[f])), f
+    from sklearn.metrics import silhouette_samples
+    np.testing.assert_allclose(sil[6], silhouette_samples(X, labs[6]), rtol=1e-10, atol=1e-12)
