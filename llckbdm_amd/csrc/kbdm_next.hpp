@@ -223,10 +223,16 @@ __global__ void __launch_bounds__(KB_KNN_TPB) k_knn_dist(const double* __restric
                 const double dj = sqrt(d2);
                 if (dj < kth && dj >= lo_d) {
                     if (dj == lo_d && skip > 0) { --skip; continue; }          // written by an earlier pass
-                    // insert into the ascending list (shift the tail down by one; equal entries keep arrival order)
-                    int q = Kp - 1;
-                    while (q > 0 && top[(q - 1) * tpb + t] > dj) { top[q * tpb + t] = top[(q - 1) * tpb + t]; --q; }
-                    top[q * tpb + t] = dj;
+                    // insert into the ascending list behind the entries <= dj (equal entries keep arrival order): the place
+                    // by bisection (dj < the last entry), then the tail moves down by one - independent LDS copies, where a
+                    // compare-and-shift loop waits for an LDS round trip per entry
+                    int lo = 0, hi = Kp - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (top[mid * tpb + t] > dj) hi = mid; else lo = mid + 1;
+                    }
+                    for (int q = Kp - 1; q > lo; --q) top[q * tpb + t] = top[(q - 1) * tpb + t];
+                    top[lo * tpb + t] = dj;
                     kth = top[(Kp - 1) * tpb + t];
                 }
             }

@@ -201,8 +201,11 @@ def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, 
     members = [(np.sort(order[starts[k]:starts[k + 1]]),) for k in range(num_clusters)]   # np.nonzero-style tuples
     if sil is None:                                            # (llc_kbdm hands over the sweep's batched silhouettes)
         sil = (engine or default_engine()).silhouette_samples(transformed_samples, labels)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        mean_sil = np.array([np.average(sil[ix]) if len(ix) else np.nan for (ix,) in members])   # llckbdm.py:299-301
+    # llckbdm.py:299-301: np.average of every cluster's silhouettes - the cluster's samples in ascending order are a slice of
+    # the sorted view (the same values in the same order, so the same bits; no fancy index, no np.average call overhead)
+    sil_sorted = np.ascontiguousarray(np.asarray(sil)[order])
+    mean_sil = np.array([sil_sorted[starts[k]:starts[k + 1]].mean() if starts[k + 1] > starts[k] else np.nan
+                         for k in range(num_clusters)])
     clustered = np.empty(num_clusters, dtype=object)
     for k, idx in enumerate(members):
         clustered[k] = idx
@@ -223,6 +226,20 @@ def _summarize_clusters(samples, clusters, summarizer=np.average):
     if summarizer is None:
         summarizer = np.average
     out = np.empty((len(index_sets), samples.shape[1]), dtype=np.float64)
+    if summarizer is np.average:
+        # the default reduction for all clusters at once: a segmented sum over the concatenated rows, divided by the cluster
+        # sizes.  np.add.reduceat adds a segment's rows in another order than np.average(rows, axis=0) does: the same means
+        # to a few ulp of the summands (tests/test_next_rows.py), 25 000 numpy calls fewer on a C2 sweep
+        counts = np.array([len(ix) for ix in index_sets])
+        nonempty = np.flatnonzero(counts)
+        out[:] = np.nan
+        if len(nonempty):
+            rows = samples[np.concatenate([index_sets[k] for k in nonempty])]
+            rows[:, 1] = 1.0 / rows[:, 1]
+            starts = np.concatenate(([0], np.cumsum(counts[nonempty])[:-1]))
+            out[nonempty] = np.add.reduceat(rows, starts, axis=0) / counts[nonempty][:, None]
+        out[:, 1] = 1.0 / out[:, 1]
+        return out
     for k, ix in enumerate(index_sets):
         rows = samples[ix]                                   # a copy (fancy index): only clustered rows are inverted
         rows[:, 1] = 1.0 / rows[:, 1]

@@ -162,3 +162,22 @@ def test_hdbscan_tree_part_against_sklearn():
         ref = HDBSCAN(min_samples=k, min_cluster_size=5, copy=True).fit(X).labels_
         assert ncl == len(set(ref.tolist()) - {-1})
         assert adjusted_rand_score(ref, out) >= 0.99
+
+
+def test_summarize_clusters_fast_path_against_the_loop():
+    """The segmented-sum form of `_summarize_clusters` (all clusters at once) against the reference's loop of
+    `np.average(rows, axis=0)` per cluster: the same means to a few ulp of the summands (another order of the additions), empty clusters
+    (NaN rows) included."""
+    import llckbdm_amd.llckbdm as M
+    rng = np.random.default_rng(3)
+    samples = np.column_stack([rng.random(5000) + 0.1, rng.random(5000) + 0.01, rng.standard_normal(5000), rng.standard_normal(5000)])
+    perm = rng.permutation(5000)
+    cuts = np.sort(rng.choice(np.arange(1, 5000), 60, replace=False))
+    clusters = [(np.sort(ix),) for ix in np.split(perm, cuts)]
+    clusters.insert(7, (np.array([], dtype=np.int64),))
+    clusters.append((np.array([4], dtype=np.int64),))
+    fast = M._summarize_clusters(samples, clusters)
+    slow = M._summarize_clusters(samples, clusters, summarizer=lambda rows, axis: np.average(rows, axis=axis))
+    # (ulps of the summands: the F / PH means sit near zero)
+    np.testing.assert_allclose(fast, slow, rtol=1e-14, atol=4 * np.finfo(float).eps, equal_nan=True)
+    assert np.isnan(fast[7]).all() and not np.isnan(np.delete(fast, 7, axis=0)).any()
