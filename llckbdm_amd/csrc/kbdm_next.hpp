@@ -374,7 +374,10 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
                 const int s = s0 + u;
                 if (s < NS) {
                     const int i = t + s * NT;
-                    const size_t row = (bestr[s] >= 0.0) ? (size_t)i : (size_t)cur;
+                    // (w >= max(core_i, core_cur): when that is no better than the sample's best edge the distance cannot
+                    // matter - the row is not streamed; exact, and the usual case for the larger min_samples)
+                    const bool need = bestr[s] >= 0.0 && fmax(corer[s], ccur) < bestr[s];
+                    const size_t row = need ? (size_t)i : (size_t)cur;
                     xa[u] = x2[2 * row];
                     xb[u] = x2[2 * row + 1];
                 }

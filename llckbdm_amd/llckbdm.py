@@ -187,7 +187,10 @@ def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, 
     if labels is None:
         labels = _fit_labels(transformed_samples, min_samples, clusterer, engine)
     labels = np.asarray(labels)
-    order = np.argsort(labels, kind="stable")                 # noise (-1) first, then cluster 0, 1, ...
+    # noise (-1) first, then cluster 0, 1, ...; STABLE: inside a label the sample indices ascend.  (16-bit keys take numpy's
+    # radix sort: several times faster on the 20 000 pooled lines of a C2 sweep, the same permutation.)
+    small = labels.size > 0 and -32768 <= labels.min() and labels.max() <= 32767
+    order = np.argsort(labels.astype(np.int16) if small else labels, kind="stable")
     sorted_labels = labels[order]
     values = np.unique(sorted_labels)
     num_clusters = int(np.count_nonzero(values >= 0))          # len(set(labels) - {-1}), llckbdm.py:285
@@ -198,7 +201,7 @@ def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, 
     # every clusterer used here numbers its clusters contiguously, and a label value that is absent gives an EMPTY
     # index set (searchsorted: start == end), never a wrong segment
     starts = np.searchsorted(sorted_labels, np.arange(num_clusters + 1))
-    members = [(np.sort(order[starts[k]:starts[k + 1]]),) for k in range(num_clusters)]   # np.nonzero-style tuples
+    members = [(order[starts[k]:starts[k + 1]].copy(),) for k in range(num_clusters)]     # np.nonzero-style tuples (ascending: stable sort)
     if sil is None:                                            # (llc_kbdm hands over the sweep's batched silhouettes)
         sil = (engine or default_engine()).silhouette_samples(transformed_samples, labels)
     # llckbdm.py:299-301: np.average of every cluster's silhouettes - the cluster's samples in ascending order are a slice of
