@@ -204,11 +204,14 @@ def _cluster_line_lists(samples, transformed_samples, min_samples, engine=None, 
     members = [(order[starts[k]:starts[k + 1]].copy(),) for k in range(num_clusters)]     # np.nonzero-style tuples (ascending: stable sort)
     if sil is None:                                            # (llc_kbdm hands over the sweep's batched silhouettes)
         sil = (engine or default_engine()).silhouette_samples(transformed_samples, labels)
-    # llckbdm.py:299-301: np.average of every cluster's silhouettes - the cluster's samples in ascending order are a slice of
-    # the sorted view (the same values in the same order, so the same bits; no fancy index, no np.average call overhead)
-    sil_sorted = np.ascontiguousarray(np.asarray(sil)[order])
-    mean_sil = np.array([sil_sorted[starts[k]:starts[k + 1]].mean() if starts[k + 1] > starts[k] else np.nan
-                         for k in range(num_clusters)])
+    # llckbdm.py:299-301: np.average of every cluster's silhouettes - a cluster is a slice of the sorted view, all the means
+    # are one segmented sum over it (another order of the additions than np.average: the same means to a few ulp)
+    sil_sorted = np.ascontiguousarray(np.asarray(sil, dtype=np.float64)[order])
+    counts = np.diff(starts)
+    mean_sil = np.full(num_clusters, np.nan)
+    nonempty = np.flatnonzero(counts)
+    if len(nonempty):
+        mean_sil[nonempty] = np.add.reduceat(sil_sorted[:starts[-1]], starts[:-1][nonempty]) / counts[nonempty]
     clustered = np.empty(num_clusters, dtype=object)
     for k, idx in enumerate(members):
         clustered[k] = idx
