@@ -532,6 +532,8 @@ class Engine:
                                                     _lib.ptr(out)))
         return out
 
+    SWEEP_CHUNK_ENTRIES = 32_000_000
+
     def silhouette_sweep(self, X, labels):
         """`silhouette_samples` for every row of `labels` (nfits x n) in one GPU call: (silhouettes[nfits, n], valid[nfits]);
         the same bits as one call per row; a row outside sklearn's precondition comes back with valid = False."""
@@ -539,8 +541,12 @@ class Engine:
         labels = np.ascontiguousarray(np.atleast_2d(labels), dtype=np.int32)
         out = np.empty(labels.shape, dtype=np.float64)
         valid = np.empty(labels.shape[0], dtype=np.int32)
-        _lib.check(self.lib.kbdm_silhouette_sweep(self.ctx, _lib.ptr(X), X.shape[0], X.shape[1], _lib.ptr(labels), labels.shape[0],
-                                                  _lib.ptr(out), _lib.ptr(valid)))
+        # a call holds two index arrays and the silhouettes of its fits on the host and on the device: at most 32 M entries each
+        step = max(1, self.SWEEP_CHUNK_ENTRIES // max(1, X.shape[0]))
+        for f0 in range(0, labels.shape[0], step):
+            lab, o, v = labels[f0:f0 + step], out[f0:f0 + step], valid[f0:f0 + step]
+            _lib.check(self.lib.kbdm_silhouette_sweep(self.ctx, _lib.ptr(X), X.shape[0], X.shape[1], _lib.ptr(lab), lab.shape[0],
+                                                      _lib.ptr(o), _lib.ptr(v)))
         return out, valid.astype(bool)
 
     def hdbscan_sweep(self, X, min_samples_list, min_cluster_size=5):

@@ -195,3 +195,9 @@ def test_silhouette_sweep_equals_one_call_per_labeling(eng):
             assert np.array_equal(sil[f], eng.silhouette_samples(X, labs[f])), f
     from sklearn.metrics import silhouette_samples
     np.testing.assert_allclose(sil[6], silhouette_samples(X, labs[6]), rtol=1e-10, atol=1e-12)
+    eng.SWEEP_CHUNK_ENTRIES = 2 * len(X) + 5                       # two fits per call: the chunked path
+    try:
+        sil2, ok2 = eng.silhouette_sweep(X, labs)
+    finally:
+        del eng.SWEEP_CHUNK_ENTRIES
+    assert np.array_equal(sil2, sil) and np.array_equal(ok2, ok)
