@@ -1853,17 +1853,18 @@ int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int
         // Prim per fit: the register-resident form for the reference's 4-dimensional samples while a thread's share fits
         // its registers (n <= 20480: a C2 ensemble pools about 20 000 lines), the general form beyond
         const size_t psm = sizeof(int) * (size_t)n;
-        if (dim == 4 && n <= 1024 * 6) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_mst_reg<6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
-            hipLaunchKernelGGL(k_prim_mst_reg<6>, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_edges);
-        } else if (dim == 4 && n <= 1024 * 12) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_mst_reg<12>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
-            hipLaunchKernelGGL(k_prim_mst_reg<12>, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_edges);
-        } else if (dim == 4 && n <= 1024 * 20) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_prim_mst_reg<20>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
-            hipLaunchKernelGGL(k_prim_mst_reg<20>, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_edges);
-        } else
+        auto prim_reg = [&](auto kern) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
+            hipLaunchKernelGGL(kern, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_core, d_edges);
+        };
+        if (dim == 4 && n <= 1024 * 6) prim_reg(k_prim_mst_reg<6>);
+        else if (dim == 4 && n <= 1024 * 12) prim_reg(k_prim_mst_reg<12>);
+        else if (dim == 4 && n <= 1024 * 20) prim_reg(k_prim_mst_reg<20>);
+        else if (dim == 4 && n <= 1024 * 30) prim_reg(k_prim_mst_reg<30, false>);
+        else if (dim == 4 && n <= 40000) prim_reg(k_prim_mst_reg<40, false>);
+        else {
             hipLaunchKernelGGL(k_prim_mst, dim3(nfits), dim3(1024), 0, st, d_x, n, dim, K, d_knn, d_ms, d_best, d_core, d_src, d_edges);
+        }
         hipMemcpyAsync(edges.data(), d_edges, sizeof(KbEdge) * edges.size(), hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { r = fail(KBDM_E_HIP, "hdbscan kernels failed"); break; }
     } while (0);

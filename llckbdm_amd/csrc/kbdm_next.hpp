@@ -331,10 +331,12 @@ __global__ void __launch_bounds__(1024) k_prim_mst(const double* __restrict__ xs
 // One step of k_prim_mst costs 16-20 us at n = 20 000 (every access a dependent trip to the L2); this form streams only
 // the coordinates: 32 B per outside sample and step.
 typedef double kb_prim_d2 __attribute__((ext_vector_type(2)));
-template <int NS>
+// CREG = false (20 480 < n <= 40 000): only the best edges stay in registers, the core distances of the fit are streamed
+// with the rows from a contiguous copy (core_all: n doubles per fit).
+template <int NS, bool CREG = true>
 __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict__ xs, int n, int K,
                                                         const double* __restrict__ knn, const int* __restrict__ min_samples,
-                                                        KbEdge* __restrict__ edges_all) {
+                                                        double* __restrict__ core_all, KbEdge* __restrict__ edges_all) {
     constexpr int NT = 1024;
     const int fit = blockIdx.x;
     const int ks = min_samples[fit];
@@ -347,17 +349,20 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
     __shared__ double xnew[5];                                 // the new vertex: coordinates, core distance
     __shared__ int cur_s;
     const kb_prim_d2* __restrict__ x2 = reinterpret_cast<const kb_prim_d2*>(xs);
-    double bestr[NS], corer[NS];
+    double* __restrict__ corem = CREG ? nullptr : core_all + (size_t)fit * n;
+    double bestr[NS], corer[CREG ? NS : 1];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int i = t + s * NT;
-        corer[s] = (i < n) ? knn[(size_t)i * K + ks - 1] : 0.0;
+        const double c = (i < n) ? knn[(size_t)i * K + ks - 1] : 0.0;
+        if (CREG) corer[s] = c;
+        else if (i < n) corem[i] = c;
         bestr[s] = (i < n && i != 0) ? inf : -1.0;            // best < 0: in the tree (or no such sample)
     }
     for (int i = t; i < n; i += NT) kb_prim_src[i] = 0;
     if (t == 0) {
         const kb_prim_d2 a = x2[0], b = x2[1];
-        xnew[0] = a.x; xnew[1] = a.y; xnew[2] = b.x; xnew[3] = b.y; xnew[4] = corer[0];
+        xnew[0] = a.x; xnew[1] = a.y; xnew[2] = b.x; xnew[3] = b.y; xnew[4] = knn[ks - 1];
         cur_s = 0;
     }
     __syncthreads();
@@ -369,6 +374,7 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
 #pragma unroll
         for (int s0 = 0; s0 < NS; s0 += 2) {
             kb_prim_d2 xa[2], xb[2];
+            double cs[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int s = s0 + u;
@@ -376,10 +382,11 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
                     const int i = t + s * NT;
                     // (w >= max(core_i, core_cur): when that is no better than the sample's best edge the distance cannot
                     // matter - the row is not streamed; exact, and the usual case for the larger min_samples)
-                    const bool need = bestr[s] >= 0.0 && fmax(corer[s], ccur) < bestr[s];
+                    const bool need = bestr[s] >= 0.0 && (!CREG || fmax(corer[s], ccur) < bestr[s]);
                     const size_t row = need ? (size_t)i : (size_t)cur;
                     xa[u] = x2[2 * row];
                     xb[u] = x2[2 * row + 1];
+                    cs[u] = CREG ? corer[s] : corem[row];
                 }
             }
 #pragma unroll
@@ -395,7 +402,7 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
                     df = xb[u].x - c2; d2 = fma(df, df, d2);
                     df = xb[u].y - c3; d2 = fma(df, df, d2);
                     double w = sqrt(d2);
-                    w = fmax(w, fmax(corer[s], ccur));
+                    w = fmax(w, fmax(cs[u], ccur));
                     if (act && w < b) { b = w; kb_prim_src[i] = cur; }
                     bestr[s] = act ? b : bestr[s];
                     if (act && b < mv) { mv = b; mi = i; }
@@ -421,10 +428,10 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
         if (mi0 == bi) {                                       // the owner of the winner (an outside sample exists while step < n - 1)
             edges[step] = KbEdge{kb_prim_src[bi], bi, bv};
             const kb_prim_d2 a = x2[2 * (size_t)bi], b = x2[2 * (size_t)bi + 1];
-            double cc = 0.0;
+            double cc = CREG ? 0.0 : corem[bi];
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                if (bi == t + s * NT) { cc = corer[s]; bestr[s] = -1.0; }
+                if (bi == t + s * NT) { if (CREG) cc = corer[s]; bestr[s] = -1.0; }
             xnew[0] = a.x; xnew[1] = a.y; xnew[2] = b.x; xnew[3] = b.y; xnew[4] = cc;
             cur_s = bi;
         }

@@ -201,3 +201,20 @@ def test_silhouette_sweep_equals_one_call_per_labeling(eng):
     finally:
         del eng.SWEEP_CHUNK_ENTRIES
     assert np.array_equal(sil2, sil) and np.array_equal(ok2, ok)
+
+
+def test_register_resident_prim_equals_the_general_kernel(eng):
+    """k_prim_mst_reg (4-dimensional samples: a fit's state in registers / LDS; five size classes, the two largest with the
+    core distances streamed) against k_prim_mst: the same points with a fifth coordinate of zeros take the general kernel
+    and add exact zeros to every squared distance - the labels must be equal arrays, ties included (half of the points
+    sit on a lattice)."""
+    rng = np.random.default_rng(23)
+    for n in (3000, 9000, 15000, 22000, 33000):
+        X = _data(rng, n - n // 2, 8, 0.3, 0)
+        lat = rng.integers(0, 12, (n // 2, 4)).astype(np.float64) * 0.25
+        X = np.concatenate([X, lat])[rng.permutation(n)]
+        ks = [1, 4, 25]
+        a, na = eng.hdbscan_sweep(X, ks)
+        b, nb = eng.hdbscan_sweep(np.column_stack([X, np.zeros(n)]), ks)
+        assert np.array_equal(a, b), n
+        assert np.array_equal(na, nb)
