@@ -1857,7 +1857,9 @@ int kbdm_hdbscan_sweep(kbdm_ctx* ctx, const double* X, int n, int dim, const int
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - 1024);
             hipLaunchKernelGGL(kern, dim3(nfits), dim3(1024), psm, st, d_x, n, K, d_knn, d_ms, d_core, d_edges);
         };
-        if (dim == 4 && n <= 1024 * 6) prim_reg(k_prim_mst_reg<6>);
+        static const int exp_stream = env_int("KBDM_PRIM_STREAM", 0);
+        if (exp_stream && dim == 4 && n <= 1024 * 20) prim_reg(k_prim_mst_reg<20, false>);
+        else if (dim == 4 && n <= 1024 * 6) prim_reg(k_prim_mst_reg<6>);
         else if (dim == 4 && n <= 1024 * 12) prim_reg(k_prim_mst_reg<12>);
         else if (dim == 4 && n <= 1024 * 20) prim_reg(k_prim_mst_reg<20>);
         else if (dim == 4 && n <= 1024 * 30) prim_reg(k_prim_mst_reg<30, false>);

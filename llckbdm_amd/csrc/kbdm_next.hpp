@@ -330,6 +330,33 @@ __global__ void __launch_bounds__(1024) k_prim_mst(const double* __restrict__ xs
 // of the winner records the edge and publishes the new vertex: two barriers per step, no serial tail.
 // One step of k_prim_mst costs 16-20 us at n = 20 000 (every access a dependent trip to the L2); this form streams only
 // the coordinates: 32 B per outside sample and step.
+// (value, index) argmin - the smaller value, the lower index among equal values: a total order, so any reduction tree gives the
+// same pair - over the 16 lanes of a DPP row (four cross-lane moves in the vector ALU; the LDS crossbar of __shfl_xor costs
+// a round trip per step), then over the wavefront's four rows by v_readlane.  Every lane ends with the wavefront's pair.
+template <int CTRL>
+__device__ __forceinline__ void kb_argmin_dpp(double& v, int& i) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, true);
+    const double ov = __hiloint2double(hi, lo);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void kb_argmin_wave(double& v, int& i) {
+    kb_argmin_dpp<0xB1>(v, i);      // quad_perm [1,0,3,2]
+    kb_argmin_dpp<0x4E>(v, i);      // quad_perm [2,3,0,1]
+    kb_argmin_dpp<0x141>(v, i);     // row_half_mirror
+    kb_argmin_dpp<0x140>(v, i);     // row_mirror: the 16 lanes of a row agree
+    double bv = v;
+    int bi = i;
+#pragma unroll
+    for (int l = 0; l < 64; l += 16) {
+        const double ov = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+        const int oi = __builtin_amdgcn_readlane(i, l);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    v = bv; i = bi;
+}
+
 typedef double kb_prim_d2 __attribute__((ext_vector_type(2)));
 // CREG = false (20 480 < n <= 40 000): only the best edges stay in registers, the core distances of the fit are streamed
 // with the rows from a contiguous copy (core_all: n doubles per fit).
@@ -366,34 +393,54 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
         cur_s = 0;
     }
     __syncthreads();
+#if defined(KB_PANEL_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long pt = wall_clock64();
+    const bool pon = t == 0 && fit == 0;
+#define KB_PRIM_MARK(ph_) do { if (pon) { const unsigned long long q_ = wall_clock64(); atomicAdd(&kb_panel_prof[20 + (ph_)], q_ - pt); pt = q_; } } while (0)
+#else
+#define KB_PRIM_MARK(ph_) do { } while (0)
+#endif
     for (int step = 0; step < n - 1; ++step) {
         const int cur = cur_s;
         const double c0 = xnew[0], c1 = xnew[1], c2 = xnew[2], c3 = xnew[3], ccur = xnew[4];
         double mv = inf;
         int mi = 0x7fffffff;
+        // (the thread index goes through an empty asm every step: left alone, the compiler keeps the 64-bit addresses of all
+        // NS rows in registers across the step loop - loop invariants that do not fit next to the state)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        // rows in flight per batch (the scheduling barrier keeps the next batch's loads - and their registers - behind this
+        // batch's arithmetic): two next to the core distances in registers, four when they are streamed
+        constexpr int PB = CREG ? 2 : (NS > 30 ? 2 : 4);
 #pragma unroll
-        for (int s0 = 0; s0 < NS; s0 += 2) {
-            kb_prim_d2 xa[2], xb[2];
-            double cs[2];
+        for (int s0 = 0; s0 < NS; s0 += PB) {
+            kb_prim_d2 xa[PB], xb[PB];
+            double cs[PB];
+            bool need[PB];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < PB; ++u) {
                 const int s = s0 + u;
                 if (s < NS) {
-                    const int i = t + s * NT;
-                    // (w >= max(core_i, core_cur): when that is no better than the sample's best edge the distance cannot
-                    // matter - the row is not streamed; exact, and the usual case for the larger min_samples)
-                    const bool need = bestr[s] >= 0.0 && (!CREG || fmax(corer[s], ccur) < bestr[s]);
-                    const size_t row = need ? (size_t)i : (size_t)cur;
-                    xa[u] = x2[2 * row];
-                    xb[u] = x2[2 * row + 1];
-                    cs[u] = CREG ? corer[s] : corem[row];
+                    const int i = tt + s * NT;
+                    // A step is bound by the bytes a compute unit can pull in (641 KB of rows at n = 20 000: 6.5 us), so a
+                    // row is requested only by the lanes that need it (masked loads): not for a sample inside the tree, and
+                    // not when max(core_i, core_cur) - a lower bound of w - is no better than the sample's best edge
+                    need[u] = bestr[s] >= 0.0 && (!CREG || fmax(corer[s], ccur) < bestr[s]);
+                    xa[u] = (kb_prim_d2){c0, c1};
+                    xb[u] = (kb_prim_d2){c2, c3};
+                    cs[u] = CREG ? corer[s] : ccur;
+                    if (need[u]) {
+                        xa[u] = x2[2 * (size_t)i];
+                        xb[u] = x2[2 * (size_t)i + 1];
+                        if (!CREG) cs[u] = corem[i];
+                    }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < PB; ++u) {
                 const int s = s0 + u;
                 if (s < NS) {
-                    const int i = t + s * NT;
+                    const int i = tt + s * NT;
                     double b = bestr[s];
                     const bool act = b >= 0.0;
                     double df = xa[u].x - c0;                  // (the same operations in the same order as k_prim_mst: an fma chain from 0)
@@ -401,30 +448,32 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
                     df = xa[u].y - c1; d2 = fma(df, df, d2);
                     df = xb[u].x - c2; d2 = fma(df, df, d2);
                     df = xb[u].y - c3; d2 = fma(df, df, d2);
-                    double w = sqrt(d2);
-                    w = fmax(w, fmax(cs[u], ccur));
-                    if (act && w < b) { b = w; kb_prim_src[i] = cur; }
-                    bestr[s] = act ? b : bestr[s];
+                    // w >= sqrt(d2) >= b whenever d2 >= b^2 (the square root is monotone and b is a double): the root, the
+                    // maxima and the comparison - four fifths of the instructions of a relaxation, and after the first steps
+                    // almost never an improvement - run only below fl(b b)(1 + 2^-51), an upper bound of b^2
+                    const double b2 = (b * b) * (1.0 + 0x1p-51);
+                    if (need[u] && (d2 < b2 || b2 < 1e-290)) {      // (a square that may have underflowed bounds nothing)
+                        double w = sqrt(d2);
+                        w = fmax(w, fmax(cs[u], ccur));
+                        if (w < b) { b = w; bestr[s] = w; kb_prim_src[i] = cur; }
+                    }
                     if (act && b < mv) { mv = b; mi = i; }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        KB_PRIM_MARK(0);
         const int mi0 = mi;
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(mv, o, 64);
-            const int oi = __shfl_xor(mi, o, 64);
-            if (ov < mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; }
-        }
+        kb_argmin_wave(mv, mi);
         if ((t & 63) == 0) { red_v[t >> 6] = mv; red_i[t >> 6] = mi; }
-        __syncthreads();
-        double bv = red_v[0];
-        int bi = red_i[0];
-#pragma unroll
-        for (int wv = 1; wv < NT / 64; ++wv) {
-            const double v = red_v[wv];
-            const int ix = red_i[wv];
-            if (v < bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
-        }
+        KB_PRIM_MARK(1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS traffic only: nobody waits for the edge store's acknowledgement)
+        KB_PRIM_MARK(2);
+        // the workgroup's pair: every wavefront reduces the 16 candidates itself (lane l < 16 takes wavefront l's)
+        double bv = ((t & 63) < NT / 64) ? red_v[t & 63] : inf;
+        int bi = ((t & 63) < NT / 64) ? red_i[t & 63] : 0x7fffffff;
+        kb_argmin_wave(bv, bi);
+        KB_PRIM_MARK(3);
         if (mi0 == bi) {                                       // the owner of the winner (an outside sample exists while step < n - 1)
             edges[step] = KbEdge{kb_prim_src[bi], bi, bv};
             const kb_prim_d2 a = x2[2 * (size_t)bi], b = x2[2 * (size_t)bi + 1];
@@ -435,7 +484,9 @@ __global__ void __launch_bounds__(1024) k_prim_mst_reg(const double* __restrict_
             xnew[0] = a.x; xnew[1] = a.y; xnew[2] = b.x; xnew[3] = b.y; xnew[4] = cc;
             cur_s = bi;
         }
-        __syncthreads();
+        KB_PRIM_MARK(4);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        KB_PRIM_MARK(5);
     }
 }
 
