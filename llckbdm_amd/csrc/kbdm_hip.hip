@@ -1777,6 +1777,13 @@ KnnGeom knn_geom(int K) {
     return g;
 }
 void launch_knn(const KnnGeom& g, hipStream_t st, const double* d_x, int n, int dim, int K, double* d_knn, double* d_lo, int* d_skip) {
+    static const int use_select = env_int("KBDM_KNN_SELECT", 1);
+    if (use_select && K <= KB_KNN_SEL_MAXK && K <= n) {            // selection with a workgroup per sample (kbdm_next.hpp)
+        int kp2 = 1;
+        while (kp2 < K) kp2 <<= 1;
+        hipLaunchKernelGGL(k_knn_select, dim3(n), dim3(256), sizeof(double) * kp2, st, d_x, n, dim, K, d_knn);
+        return;
+    }
     for (int koff = 0; koff < K; koff += g.Kp) {
         const int kp = std::min(g.Kp, K - koff);
         const size_t lds = ((size_t)kp * g.tpb + (size_t)g.tpb * KB_SIL_MAXDIM) * sizeof(double);
