@@ -218,3 +218,21 @@ def test_register_resident_prim_equals_the_general_kernel(eng):
         b, nb = eng.hdbscan_sweep(np.column_stack([X, np.zeros(n)]), ks)
         assert np.array_equal(a, b), n
         assert np.array_equal(na, nb)
+
+
+def test_llc_kbdm_with_batched_silhouettes_equals_fit_by_fit(eng):
+    """llc_kbdm scores the sweep with ONE kbdm_silhouette_sweep call; an engine without that entry (the CPU tests' stand-in, an
+    older library) is scored fit by fit: the same result, bit for bit."""
+    from llckbdm_amd import datasets
+    from llckbdm_amd.llckbdm import llc_kbdm
+    sig = np.atleast_2d(datasets.config2(seed=3)[0])[0][:768]
+
+    class FitByFit:
+        def __getattr__(self, name):
+            if name == "silhouette_sweep":
+                raise AttributeError(name)
+            return getattr(eng, name)
+    a = llc_kbdm(sig, datasets.DWELL, range(80, 96), p=1, l=30, engine=eng)
+    b = llc_kbdm(sig, datasets.DWELL, range(80, 96), p=1, l=30, engine=FitByFit())
+    assert len(a.line_list) > 0
+    assert np.array_equal(a.line_list, b.line_list) and a.rmse == b.rmse and np.array_equal(a.silhouette, b.silhouette)
